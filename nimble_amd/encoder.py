@@ -1,0 +1,412 @@
+"""Test-vector / synthetic-table generator: a numpy writer for the nine
+production stream encodings of Nimble (uncompressed payloads only).
+
+This is the *input fabricator* for tests and benchmarks -- the reference's own
+writer cannot be built offline.  Byte layouts follow the reference encoders:
+
+* prefix ............ dwio/nimble/encodings/common/EncodingPrefix.h:41-54
+* Trivial ........... dwio/nimble/encodings/TrivialEncoding.h:303-330,
+                      TrivialEncoding.cpp:170-231 (string), :383-427 (bool)
+* FixedBitWidth ..... dwio/nimble/encodings/FixedBitWidthEncoding.h:351-412
+* RLE ............... dwio/nimble/encodings/RLEEncoding.h:62-85,178-226,758-766
+* Dictionary ........ dwio/nimble/encodings/DictionaryEncoding.h:391-488
+* Nullable .......... dwio/nimble/encodings/NullableEncoding.h:370-405
+* SparseBool ........ dwio/nimble/encodings/SparseBoolEncoding.cpp:178-239
+* Constant .......... dwio/nimble/encodings/ConstantEncoding.h:163-200
+* MainlyConstant .... dwio/nimble/encodings/MainlyConstantEncoding.h:558-570,863-915
+* Varint ............ dwio/nimble/encodings/VarintEncoding.h:164-211
+* chunk framing ..... dwio/nimble/common/ChunkHeader.h:43-47
+
+Unlike the reference writer there is no selection policy: the caller names the
+cascade explicitly with the spec classes below (the same role the reference's
+tests give to TestTrivialEncodingSelectionPolicy / hand-assembled cascades).
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass, field
+from typing import Optional, Sequence, Union
+
+import numpy as np
+
+from . import wire as W
+
+__all__ = [
+    "StringColumn", "Trivial", "FixedBitWidth", "Varint", "Constant", "RLE",
+    "Dictionary", "Nullable", "SparseBool", "MainlyConstant", "encode",
+    "encode_nullable", "chunk", "stream", "bitpack", "varint_bytes",
+    "bits_required",
+]
+
+
+# --------------------------------------------------------------------------
+# value containers
+# --------------------------------------------------------------------------
+@dataclass
+class StringColumn:
+    """A column of byte strings held as (lengths, concatenated bytes)."""
+
+    lengths: np.ndarray  # uint32[n]
+    blob: np.ndarray  # uint8[sum(lengths)]
+
+    def __post_init__(self):
+        self.lengths = np.ascontiguousarray(self.lengths, dtype=np.uint32)
+        self.blob = np.ascontiguousarray(self.blob, dtype=np.uint8)
+        assert int(self.lengths.sum(dtype=np.uint64)) == self.blob.size
+
+    def __len__(self):
+        return int(self.lengths.size)
+
+    @staticmethod
+    def from_list(items: Sequence[bytes]) -> "StringColumn":
+        lengths = np.fromiter((len(s) for s in items), dtype=np.uint32, count=len(items))
+        blob = np.frombuffer(b"".join(items), dtype=np.uint8)
+        return StringColumn(lengths, blob)
+
+    def offsets(self) -> np.ndarray:
+        off = np.zeros(self.lengths.size + 1, dtype=np.uint64)
+        np.cumsum(self.lengths, dtype=np.uint64, out=off[1:])
+        return off
+
+    def to_list(self):
+        off = self.offsets()
+        raw = self.blob.tobytes()
+        return [raw[int(off[i]):int(off[i + 1])] for i in range(len(self))]
+
+    def take(self, indices: np.ndarray) -> "StringColumn":
+        indices = np.asarray(indices, dtype=np.int64)
+        off = self.offsets()
+        lens = self.lengths[indices]
+        total = int(lens.sum(dtype=np.uint64))
+        if total == 0:
+            return StringColumn(lens, np.zeros(0, dtype=np.uint8))
+        starts = off[indices].astype(np.int64)
+        out_off = np.zeros(indices.size + 1, dtype=np.int64)
+        np.cumsum(lens, dtype=np.int64, out=out_off[1:])
+        # byte gather: position p of row r reads blob[starts[r] + p - out_off[r]]
+        row_of = np.repeat(np.arange(indices.size, dtype=np.int64), lens.astype(np.int64))
+        src = starts[row_of] + (np.arange(total, dtype=np.int64) - out_off[row_of])
+        return StringColumn(lens, self.blob[src])
+
+
+Values = Union[np.ndarray, StringColumn]
+
+
+# --------------------------------------------------------------------------
+# cascade specs
+# --------------------------------------------------------------------------
+@dataclass
+class Trivial:
+    lengths: object = None  # string only: encoding of the uint32 lengths
+
+
+@dataclass
+class FixedBitWidth:
+    exact_bits: bool = False  # Encoding::Options::fixedBitWidthUseExactBits
+    bit_width: Optional[int] = None  # force a width (>= required)
+    baseline: Optional[int] = None  # force a baseline (<= min)
+
+
+@dataclass
+class Varint:
+    pass
+
+
+@dataclass
+class Constant:
+    pass
+
+
+@dataclass
+class RLE:
+    lengths: object = field(default_factory=FixedBitWidth)
+    values: object = field(default_factory=FixedBitWidth)
+
+
+@dataclass
+class Dictionary:
+    alphabet: object = field(default_factory=Trivial)
+    indices: object = field(default_factory=FixedBitWidth)
+
+
+@dataclass
+class Nullable:
+    data: object = field(default_factory=Trivial)
+    nulls: object = field(default_factory=Trivial)
+
+
+@dataclass
+class SparseBool:
+    indices: object = field(default_factory=FixedBitWidth)
+
+
+@dataclass
+class MainlyConstant:
+    is_common: object = field(default_factory=SparseBool)
+    other: object = field(default_factory=Trivial)
+
+
+# --------------------------------------------------------------------------
+# primitives
+# --------------------------------------------------------------------------
+def bits_required(v: int) -> int:
+    """Bits needed for `v`; 1 for zero (a zero width is never written)."""
+    return max(1, int(v).bit_length())
+
+
+def _write_varint(v: int) -> bytes:
+    out = bytearray()
+    while v >= 128:  # dwio/nimble/common/Varint.h:70-76
+        out.append(0x80 | (v & 0x7F))
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def prefix(enc: int, dtype: int, rows: int, varint_rows: bool = False) -> bytes:
+    if varint_rows:
+        return bytes([enc, dtype]) + _write_varint(rows)
+    return struct.pack("<BBI", enc, dtype, rows)
+
+
+def bitpack(values: np.ndarray, width: int) -> bytes:
+    """LSB-first pack: value i occupies bits [i*w, (i+1)*w) of the byte stream;
+    result is ceil(n*w/8) + 7 bytes (FixedBitArray::bufferSize)."""
+    assert 1 <= width <= 64
+    v = np.ascontiguousarray(values).astype(np.uint64, copy=False)
+    n = v.size
+    nbytes = (n * width + 7) // 8
+    if n == 0:
+        return bytes(W.FBA_SLOP)
+    groups = (n + 63) // 64
+    padded = np.zeros(groups * 64, dtype=np.uint64)
+    padded[:n] = v
+    if width < 64:
+        assert int(padded.max()) < (1 << width), "value does not fit bit width"
+    padded = padded.reshape(groups, 64)
+    words = np.zeros((groups, width), dtype=np.uint64)  # 64 values = `width` words
+    for j in range(64):
+        bit0 = j * width
+        wi, sh = bit0 >> 6, bit0 & 63
+        col = padded[:, j]
+        words[:, wi] |= col << np.uint64(sh)
+        if sh + width > 64:
+            words[:, wi + 1] |= col >> np.uint64(64 - sh)
+    raw = words.reshape(-1).view(np.uint8)[:nbytes]
+    return raw.tobytes() + bytes(W.FBA_SLOP)
+
+
+def varint_bytes(values: np.ndarray) -> bytes:
+    """LEB128, low 7 bits first (dwio/nimble/common/Varint.h:70-76)."""
+    v = np.ascontiguousarray(values).astype(np.uint64, copy=False)
+    n = v.size
+    if n == 0:
+        return b""
+    sizes = np.ones(n, dtype=np.int64)
+    for k in range(1, 10):
+        sizes += (v >= np.uint64(1 << (7 * k))).astype(np.int64)
+    offs = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(sizes, out=offs[1:])
+    out = np.zeros(int(offs[-1]), dtype=np.uint8)
+    for k in range(10):
+        m = sizes > k
+        if not m.any():
+            break
+        byte = ((v[m] >> np.uint64(7 * k)) & np.uint64(0x7F)).astype(np.uint8)
+        byte |= (sizes[m] > k + 1).astype(np.uint8) << 7
+        out[offs[:-1][m] + k] = byte
+    return out.tobytes()
+
+
+def _phys(values: np.ndarray, dtype: int) -> np.ndarray:
+    """Reinterpret `values` as the unsigned physical type of `dtype`."""
+    pt = W.physical_dtype(dtype)
+    a = np.ascontiguousarray(values)
+    if a.dtype.itemsize != np.dtype(pt).itemsize:
+        raise ValueError(f"array itemsize {a.dtype.itemsize} does not match data type {dtype}")
+    return a.view(pt)
+
+
+def _bitmap(bools: np.ndarray) -> bytes:
+    b = np.ascontiguousarray(bools).astype(np.uint8, copy=False)
+    return np.packbits(b, bitorder="little").tobytes() + bytes(W.FBA_SLOP)
+
+
+def _value_bytes(value, dtype: int) -> bytes:
+    if dtype == W.STRING:
+        return struct.pack("<I", len(value)) + bytes(value)
+    if dtype == W.BOOL:
+        return bytes([1 if value else 0])
+    return np.array([value]).astype(W.physical_dtype(dtype), copy=False).tobytes() if not isinstance(
+        value, np.generic) else np.array([value]).view(W.physical_dtype(dtype)).tobytes()
+
+
+# --------------------------------------------------------------------------
+# encoders
+# --------------------------------------------------------------------------
+def encode(spec, values: Values, dtype: int, varint_rows: bool = False) -> bytes:
+    """Serialise `values` (numpy array of the physical/logical type, bool array,
+    or StringColumn) with the cascade `spec`.  Returns one encoding's bytes."""
+    vr = varint_rows
+    if dtype == W.STRING:
+        assert isinstance(values, StringColumn)
+        n = len(values)
+    else:
+        values = np.ascontiguousarray(values)
+        n = int(values.size)
+        if dtype == W.BOOL:
+            values = values.astype(np.bool_, copy=False)
+        else:
+            values = _phys(values, dtype)
+
+    if isinstance(spec, Trivial):
+        head = prefix(W.TRIVIAL, dtype, n, vr) + bytes([W.UNCOMPRESSED])
+        if dtype == W.STRING:
+            lens = encode(spec.lengths or FixedBitWidth(), values.lengths, W.UINT32, vr)
+            return head + struct.pack("<I", len(lens)) + lens + values.blob.tobytes()
+        if dtype == W.BOOL:
+            return head + _bitmap(values)
+        return head + values.tobytes()
+
+    if isinstance(spec, FixedBitWidth):
+        assert W.is_numeric(dtype)
+        lo = int(values.min()) if n else 0
+        hi = int(values.max()) if n else 0
+        base = lo if spec.baseline is None else int(spec.baseline)
+        assert base <= lo
+        width = bits_required(hi - base)
+        if spec.bit_width is not None:
+            assert spec.bit_width >= width
+            width = spec.bit_width
+        elif not spec.exact_bits:
+            width = (width + 7) // 8 * 8
+        residual = (values - values.dtype.type(base)) if n else values
+        pt = W.physical_dtype(dtype)
+        return (prefix(W.FIXED_BIT_WIDTH, dtype, n, vr) + bytes([W.UNCOMPRESSED]) +
+                np.array([base], dtype=pt).tobytes() + bytes([width]) + bitpack(residual, width))
+
+    if isinstance(spec, Varint):
+        assert W.elem_bytes(dtype) in (4, 8) and W.is_numeric(dtype)
+        base = int(values.min()) if n else 0
+        pt = W.physical_dtype(dtype)
+        residual = (values - values.dtype.type(base)) if n else values
+        return (prefix(W.VARINT, dtype, n, vr) + np.array([base], dtype=pt).tobytes() +
+                varint_bytes(residual))
+
+    if isinstance(spec, Constant):
+        assert n > 0, "ConstantEncoding cannot be empty"
+        if dtype == W.STRING:
+            first = values.to_list()[0] if n < 1000 else values.take(np.array([0])).blob.tobytes()
+            assert (values.lengths == values.lengths[0]).all()
+            return prefix(W.CONSTANT, dtype, n, vr) + struct.pack("<I", len(first)) + first
+        assert (values == values[0]).all(), "ConstantEncoding requires constant data"
+        if dtype == W.BOOL:
+            return prefix(W.CONSTANT, dtype, n, vr) + bytes([int(values[0])])
+        return prefix(W.CONSTANT, dtype, n, vr) + values[:1].tobytes()
+
+    if isinstance(spec, RLE):
+        if dtype == W.STRING:
+            ids = _string_ids(values)
+            change = np.ones(n, dtype=bool)
+            change[1:] = ids[1:] != ids[:-1]
+        else:
+            change = np.ones(n, dtype=bool)
+            change[1:] = values[1:] != values[:-1]
+        starts = np.flatnonzero(change)
+        lengths = np.diff(np.append(starts, n)).astype(np.uint32)
+        lens = encode(spec.lengths, lengths, W.UINT32, vr)
+        head = prefix(W.RLE, dtype, n, vr) + struct.pack("<I", len(lens)) + lens
+        if dtype == W.BOOL:
+            return head + bytes([int(values[0]) if n else 0])
+        run_values = values.take(starts) if dtype == W.STRING else values[starts]
+        return head + encode(spec.values, run_values, dtype, vr)
+
+    if isinstance(spec, Dictionary):
+        assert dtype != W.BOOL
+        keys = _string_ids(values) if dtype == W.STRING else values
+        # alphabet in first-occurrence order (DictionaryEncoding.h:432-456)
+        uniq, first_idx, inverse = np.unique(keys, return_index=True, return_inverse=True)
+        order = np.argsort(first_idx, kind="stable")
+        rank = np.empty_like(order)
+        rank[order] = np.arange(order.size)
+        indices = rank[inverse].astype(np.uint32)
+        first_sorted = first_idx[order]
+        alphabet = values.take(first_sorted) if dtype == W.STRING else values[first_sorted]
+        alpha = encode(spec.alphabet, alphabet, dtype, vr)
+        return (prefix(W.DICTIONARY, dtype, n, vr) + struct.pack("<I", len(alpha)) + alpha +
+                encode(spec.indices, indices, W.UINT32, vr))
+
+    if isinstance(spec, SparseBool):
+        assert dtype == W.BOOL
+        set_count = int(values.sum())
+        if set_count > (n >> 1):  # SparseBoolEncoding.cpp:190-196
+            sparse_value, idx = False, np.flatnonzero(~values)
+        else:
+            sparse_value, idx = True, np.flatnonzero(values)
+        idx = np.append(idx, n).astype(np.uint32)  # sentinel, :215-217
+        return (prefix(W.SPARSE_BOOL, dtype, n, vr) + bytes([int(sparse_value)]) +
+                encode(spec.indices, idx, W.UINT32, vr))
+
+    if isinstance(spec, MainlyConstant):
+        assert dtype != W.BOOL and n > 0
+        keys = _string_ids(values) if dtype == W.STRING else values
+        uniq, first_idx, counts = np.unique(keys, return_index=True, return_counts=True)
+        if dtype == W.STRING:
+            # ties -> smaller string; order candidate keys by actual bytes
+            cand = np.flatnonzero(counts == counts.max())
+            strs = values.take(first_idx[cand]).to_list()
+            best = cand[min(range(len(strs)), key=lambda i: strs[i])]
+        else:
+            best = int(np.flatnonzero(counts == counts.max())[0])  # uniq sorted -> smaller value
+        is_common = keys == uniq[best]
+        other_rows = np.flatnonzero(~is_common)
+        other = values.take(other_rows) if dtype == W.STRING else values[other_rows]
+        ic = encode(spec.is_common, is_common, W.BOOL, vr)
+        ov = encode(spec.other, other, dtype, vr)
+        if dtype == W.STRING:
+            cv = values.take(np.array([first_idx[best]])).blob.tobytes()
+            common = struct.pack("<I", len(cv)) + cv
+        else:
+            common = values[first_idx[best]:first_idx[best] + 1].tobytes()
+        return (prefix(W.MAINLY_CONSTANT, dtype, n, vr) + struct.pack("<I", len(ic)) + ic +
+                struct.pack("<I", len(ov)) + ov + common)
+
+    if isinstance(spec, Nullable):
+        raise TypeError("use encode_nullable() for Nullable cascades")
+    raise TypeError(f"unknown spec {spec!r}")
+
+
+def encode_nullable(spec: Nullable, non_null_values: Values, non_null_mask: np.ndarray,
+                    dtype: int, varint_rows: bool = False) -> bytes:
+    """Nullable{data, nulls}: `non_null_values` holds only the non-null rows
+    (densely), `non_null_mask[i]` is True when row i is NOT null
+    (NullableEncoding.h:370-405)."""
+    mask = np.ascontiguousarray(non_null_mask).astype(np.bool_, copy=False)
+    n = int(mask.size)
+    nn = int(mask.sum())
+    assert (len(non_null_values) if dtype == W.STRING else int(np.asarray(non_null_values).size)) == nn
+    data = encode(spec.data, non_null_values, dtype, varint_rows)
+    nulls = encode(spec.nulls, mask, W.BOOL, varint_rows)
+    return prefix(W.NULLABLE, dtype, n, varint_rows) + struct.pack("<I", len(data)) + data + nulls
+
+
+def _string_ids(col: StringColumn) -> np.ndarray:
+    """Dense integer id per row, equal ids <=> equal strings."""
+    items = col.to_list()
+    table = {}
+    ids = np.empty(len(items), dtype=np.int64)
+    for i, s in enumerate(items):
+        ids[i] = table.setdefault(s, len(table))
+    return ids
+
+
+# --------------------------------------------------------------------------
+# chunk / stream framing
+# --------------------------------------------------------------------------
+def chunk(encoding_bytes: bytes, compression: int = W.UNCOMPRESSED) -> bytes:
+    """u32 length | u8 CompressionType | payload (ChunkHeader.h:43-47)."""
+    return struct.pack("<IB", len(encoding_bytes), compression) + encoding_bytes
+
+
+def stream(encodings: Sequence[bytes]) -> bytes:
+    return b"".join(chunk(e) for e in encodings)
