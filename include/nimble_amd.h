@@ -1,0 +1,168 @@
+/*
+ * nimble_amd.h -- C ABI of the MI355X-native decoder for Nimble's cascading
+ * stream encodings (Trivial, FixedBitWidth, RLE, Dictionary, Nullable,
+ * SparseBool, Constant, MainlyConstant, Varint).
+ *
+ * The library replaces, for a *batch* of encoded chunks, what the reference
+ * does one chunk at a time on the CPU:
+ *
+ *   EncodingFactory::create(pool, chunkBytes, stringBufferFactory)
+ *       dwio/nimble/encodings/common/EncodingFactory.h:40-51,
+ *       dwio/nimble/encodings/common/EncodingFactory.cpp:62-173
+ *   followed by Encoding::materialize / materializeNullable over all rows
+ *       dwio/nimble/encodings/common/Encoding.h:231-260
+ *
+ * The reference has no FFI; a maintainer binds these entry points from a
+ * subclass of nimble::EncodingFactory / an implementation of nimble::Decoder
+ * (dwio/nimble/velox/Decoder.h:27-56), see INTEGRATION.md.
+ *
+ * Conventions: plain pointers and sizes only; every function returns an
+ * nbl_status (0 = ok); nbl_last_error() gives the message of the calling
+ * thread's last failure.  Device pointers are ordinary HIP device addresses,
+ * `stream` is a hipStream_t passed as void*.  Nothing here allocates device
+ * memory: the caller owns the arena (encoded bytes), output and work buffers,
+ * sized from nbl_plan_info.
+ */
+#ifndef NIMBLE_AMD_H_
+#define NIMBLE_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int nbl_status;
+enum {
+  NBL_OK = 0,
+  /* Malformed bytes: what the reference reports through NIMBLE_CHECK /
+   * NIMBLE_UNREACHABLE (dwio/nimble/common/Exceptions.h:111-155). */
+  NBL_ERR_CORRUPT = 1,
+  /* Well-formed Nimble that this library does not decode on the GPU
+   * (compressed payloads, experimental encodings): the caller delegates the
+   * chunk to the reference's CPU EncodingFactory. */
+  NBL_ERR_UNSUPPORTED = 2,
+  NBL_ERR_HIP = 3,      /* a HIP runtime call failed */
+  NBL_ERR_ARGUMENT = 4, /* bad argument from the caller */
+  NBL_ERR_DEVICE_DATA = 5 /* a kernel found inconsistent payload data */
+};
+
+/* Mirrors the fields of Encoding::Options that affect decode
+ * (dwio/nimble/encodings/common/Encoding.h:115-175). */
+typedef struct nbl_options {
+  uint32_t struct_size;            /* sizeof(nbl_options) */
+  uint32_t use_varint_row_count;   /* Encoding::Options::useVarintRowCount */
+} nbl_options;
+
+typedef struct nbl_plan nbl_plan;
+
+/* Sizes the caller needs to allocate buffers for one planned batch. */
+typedef struct nbl_plan_info {
+  uint32_t n_chunks;
+  uint32_t n_nodes;        /* encodings in all cascade trees */
+  uint32_t n_launches;     /* kernel launches nbl_decode_batch_device issues */
+  uint32_t max_depth;      /* deepest cascade */
+  uint64_t arena_bytes;    /* device bytes for the encoded image (input span + slop) */
+  uint64_t out_bytes;      /* device bytes for all decoded outputs */
+  uint64_t work_bytes;     /* device bytes for descriptors + intermediates */
+  uint64_t descriptor_bytes; /* leading part of work that nbl_plan_upload fills */
+  uint64_t total_rows;     /* sum of top-level row counts */
+  uint64_t encoded_bytes;  /* sum of chunk sizes (B_enc, slop included) */
+  uint64_t decoded_bytes;  /* bytes of decoded output written (B_out) */
+} nbl_plan_info;
+
+/* Where one chunk's decoded output lives inside the output buffer. */
+typedef struct nbl_chunk_layout {
+  uint32_t rows;
+  uint8_t encoding_type;   /* EncodingType of the top-level encoding */
+  uint8_t data_type;       /* DataType */
+  uint8_t nullable;        /* 1 when the top-level encoding is Nullable */
+  uint8_t elem_bytes;      /* numeric: sizeof(physicalType); bool: 1; string: 8 */
+  uint32_t non_null_rows;  /* rows of the non-null child (== rows when !nullable) */
+  uint32_t reserved;
+  /* numeric: physicalType[rows]; bool: one byte (0/1) per row, as
+   * Encoding::materialize yields; string: {uint32 offset, uint32 length}[rows]
+   * relative to string_offset.  Null rows hold physicalType() / an empty view. */
+  uint64_t values_offset;
+  uint64_t values_bytes;
+  /* Nullable only: bitmap, bit i = 1 when row i is non-null (LSB first),
+   * ceil(rows/64)*8 bytes, bits past `rows` zero. */
+  uint64_t nulls_offset;
+  uint64_t nulls_bytes;
+  /* string only: the bytes the reference would have placed in memory obtained
+   * from stringBufferFactory. */
+  uint64_t string_offset;
+  uint64_t string_bytes;
+} nbl_chunk_layout;
+
+/*
+ * Walks the encoding headers of `n_chunks` top-level encodings (no payload is
+ * decoded) and builds the decode tree, the output layout and the launch list.
+ * Chunk i occupies [base + offsets[i], base + offsets[i] + sizes[i]) in host
+ * memory; the device arena must be a byte image of the span
+ * [base, base + max(offsets[i] + sizes[i])), so chunk offsets carry over
+ * unchanged (no alignment requirement).  `chunk` here is the payload of one
+ * stream chunk, i.e. the bytes after the 5-byte chunk header
+ * (dwio/nimble/common/ChunkHeader.h:28-40); use nbl_split_stream first.
+ * Replaces the recursive constructor walk of EncodingFactory::create.
+ */
+nbl_status nbl_plan_batch(const uint8_t* base, const uint64_t* offsets,
+                          const uint64_t* sizes, uint32_t n_chunks,
+                          const nbl_options* options, nbl_plan** plan_out);
+
+void nbl_plan_free(nbl_plan* plan);
+
+nbl_status nbl_plan_get_info(const nbl_plan* plan, nbl_plan_info* info);
+
+nbl_status nbl_plan_get_chunk_layout(const nbl_plan* plan, uint32_t chunk,
+                                     nbl_chunk_layout* layout);
+
+/*
+ * Splits one stream into its chunks: u32 length | u8 CompressionType | bytes
+ * (InMemoryChunkedStream::nextChunk, dwio/nimble/velox/ChunkedStream.cpp:36-72).
+ * Writes up to `capacity` (offset, size) pairs of the chunk payloads relative
+ * to `stream` and the total count to *n_chunks.  A compressed chunk yields
+ * NBL_ERR_UNSUPPORTED, bad framing NBL_ERR_CORRUPT.
+ */
+nbl_status nbl_split_stream(const uint8_t* stream, uint64_t size,
+                            uint64_t* offsets, uint64_t* sizes,
+                            uint32_t capacity, uint32_t* n_chunks);
+
+/* Copies the plan's descriptor tables to the front of `d_work`
+ * (info.descriptor_bytes, asynchronous on `stream`).  Must precede
+ * nbl_decode_batch_device on the same stream for a given d_work. */
+nbl_status nbl_plan_upload(nbl_plan* plan, void* d_work, void* stream);
+
+/*
+ * Decodes the whole batch: every cascade level is one batched kernel launch
+ * over all chunks.  Asynchronous on `stream`; no allocation, no host
+ * synchronisation.  Replaces Encoding::materialize / materializeNullable of
+ * every chunk.  `d_arena` holds the encoded image (info.arena_bytes readable),
+ * `d_out` receives the outputs (info.out_bytes), `d_work` is scratch
+ * (info.work_bytes) already initialised by nbl_plan_upload.
+ */
+nbl_status nbl_decode_batch_device(const nbl_plan* plan, const void* d_arena,
+                                   void* d_out, void* d_work, void* stream);
+
+/* Synchronises `stream` and reports whether any kernel flagged inconsistent
+ * data (e.g. run lengths that do not sum to the row count, dictionary index
+ * out of range): NBL_OK or NBL_ERR_DEVICE_DATA. */
+nbl_status nbl_decode_status(const nbl_plan* plan, const void* d_work, void* stream);
+
+/* Number of launches and, for launch i, the kernel name and tile count (for
+ * profiling and roofline accounting). */
+nbl_status nbl_plan_get_launch(const nbl_plan* plan, uint32_t launch,
+                               const char** kernel_name, uint32_t* n_tiles);
+
+/* Message of the calling thread's most recent failure (never NULL). */
+const char* nbl_last_error(void);
+
+/* Library / device introspection: returns the gfx arch string the kernels
+ * were built for ("gfx950"). */
+const char* nbl_build_arch(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NIMBLE_AMD_H_ */

@@ -1,0 +1,120 @@
+// Descriptor tables shared by the host planner and the HIP kernels.
+//
+// A planned batch is a flat table of nodes (one per encoding in the cascade
+// trees) plus, per kernel launch, a table of tiles.  Everything a kernel needs
+// is addressed as a byte offset into one of three device buffers:
+//   arena : byte image of the encoded chunks (read only)
+//   out   : decoded outputs of the top-level encodings
+//   work  : descriptor tables, scan partials and materialised intermediates
+#pragma once
+#include <stdint.h>
+
+namespace nbl {
+
+// How a consumer reads element i of a column produced by a child encoding.
+// Leaves of the cascade (FixedBitWidth, numeric Trivial, Constant, bool
+// Trivial) are never materialised for their parent: the parent's kernel reads
+// the encoded payload through this accessor, which fuses the two levels.
+enum ColKind : uint8_t {
+  COL_NONE = 0,
+  COL_MAT_WORK = 1,   // element array in `work` (aligned to 16 bytes)
+  COL_MAT_OUT = 2,    // element array in `out`
+  COL_FBW = 3,        // bit-packed payload in `arena`: (bits >> .. & mask) + base
+  COL_RAW = 4,        // little-endian elements in `arena`, any alignment
+  COL_CONST = 5,      // every element == base
+  COL_BITS_WORK = 6,  // bool column as bitmap words (uint64, LSB first) in `work`
+  COL_BITS_RAW = 7,   // bool column as bitmap bytes in `arena`, any alignment
+};
+
+struct ColRef {
+  uint64_t off;    // byte offset into the buffer selected by `kind`
+  uint64_t base;   // FBW baseline / CONST value (bool: 0 or 1)
+  uint32_t rows;   // number of elements
+  uint8_t kind;    // ColKind
+  uint8_t width;   // FBW bit width (0..64)
+  uint8_t es;      // bytes per element (1, 2, 4, 8); bool bitmaps: 0
+  uint8_t pad;
+};
+
+// Kernel ids (also the index into the launch-name table).
+enum KernelId : uint32_t {
+  K_MATERIALIZE = 0,   // root leaf -> out               (src = c0)
+  K_BITS_TO_BYTES,     // bool bitmap -> one byte per row (src = c0)
+  K_REDUCE_SUM,        // tile sums of a uint32 column    (src = c0)
+  K_REDUCE_POPC,       // tile popcounts of a bitmap      (src = sel, invert flag)
+  K_REDUCE_VARINT,     // tile counts of varint terminator bytes
+  K_SCAN_TILES,        // per node exclusive scan of its tile partials
+  K_RLE_ENDS,          // inclusive run ends
+  K_RLE_EXPAND,        // runs -> rows
+  K_RLE_EXPAND_BOOL,   // bool runs -> bitmap
+  K_SPARSE_BITS,       // sorted positions -> bitmap
+  K_SELECT_SCATTER,    // Nullable / MainlyConstant
+  K_DICT_GATHER,       // alphabet[indices[i]]
+  K_VARINT_DECODE,
+  K_STRING_VIEWS,      // lengths -> {offset,len}
+  K_COPY_BYTES,        // string blobs arena -> out
+  K_SELECT_BITS,       // Nullable<bool>: scatter a bitmap by a bitmap
+  K_COUNT
+};
+
+enum NodeFlags : uint32_t {
+  NF_INVERT_SEL = 1u << 0,   // select where the bit is 0 (MainlyConstant isCommon)
+  NF_WRITE_NULLS = 1u << 1,  // also emit the selection bitmap to out (Nullable root)
+  NF_SPARSE_VALUE = 1u << 2, // SparseBool: listed positions are 1
+  NF_FIRST_TRUE = 1u << 3,   // RLE<bool>: first run is true
+};
+
+// Status bits OR-ed into work[status_off] by kernels that meet inconsistent data.
+enum StatusBits : uint32_t {
+  ST_RLE_SUM_MISMATCH = 1u << 0,   // run lengths do not add up to rowCount
+  ST_DICT_INDEX_RANGE = 1u << 1,   // dictionary index >= alphabet size
+  ST_SELECT_COUNT = 1u << 2,       // set bits != rows of the values child
+  ST_VARINT_COUNT = 1u << 3,       // fewer varints than rowCount
+  ST_STRING_BYTES = 1u << 4,       // string lengths exceed the blob
+};
+
+struct NodeDesc {
+  ColRef self;        // where the node's own output goes
+  ColRef c0;          // first input (lengths / indices / source of a root leaf ...)
+  ColRef c1;          // second input (run values / alphabet / selected values ...)
+  ColRef sel;         // bitmap input (nulls / isCommon)
+  uint64_t aux;       // fill value (Nullable: 0, MainlyConstant: common value);
+                      // K_COPY_BYTES: byte count; K_STRING_VIEWS: blob base offset
+  uint64_t aux_off;   // second array: run ends (work) / nulls bitmap (out) / copy src (arena)
+  uint64_t aux2;      // K_STRING_VIEWS: blob bytes; varint: payload byte count
+  uint32_t rows;      // rows of this node
+  uint32_t flags;     // NodeFlags
+  uint32_t part_base; // first slot of this node in the tile-partials array
+  uint32_t n_parts;   // number of scan tiles
+  uint32_t total_idx; // slot in the node-totals array
+  uint32_t pad;
+};
+
+struct TileRef {
+  uint32_t node;   // index into the node table
+  uint32_t tile;   // tile number within that node for this kernel
+};
+
+// Addresses handed to every kernel.
+struct KArgs {
+  const uint8_t* arena;
+  uint8_t* out;
+  uint8_t* work;
+  const NodeDesc* nodes;   // in work
+  const TileRef* tiles;    // in work, already offset to this launch's first tile
+  uint32_t* parts;         // tile partials (work)
+  uint32_t* totals;        // per-node totals (work)
+  uint32_t* status;        // status word (work)
+  uint32_t n_tiles;
+};
+
+// Tile geometry: every row-producing kernel writes 16 KiB of output per
+// workgroup of 256 threads (four 16-byte stores per thread).
+constexpr uint32_t kBlock = 256;
+constexpr uint32_t kTileBytes = 16384;
+constexpr uint32_t kScanTile = 2048;        // elements per tile of the u32 scans
+constexpr uint32_t kBitTileWords = 256;     // 64-bit words per bitmap tile (16384 rows)
+constexpr uint32_t kBitTileRows = kBitTileWords * 64;
+constexpr uint32_t kVarintTile = 4096;      // encoded bytes per varint tile
+
+}  // namespace nbl

@@ -1,0 +1,805 @@
+// Host side of the C ABI: header-only walk of the cascade trees of a batch of
+// chunks, output / scratch layout, level-ordered launch list.
+//
+// The walk mirrors what the reference's constructors do when
+// EncodingFactory::create builds an Encoding tree
+// (dwio/nimble/encodings/common/EncodingFactory.cpp:62-164 and the per-encoding
+// constructors cited below) and what EncodingLayoutCapture::capture does without
+// decoding payloads (dwio/nimble/encodings/common/EncodingLayout.cpp:171-405),
+// but over a whole batch and without touching payload bytes.
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/nimble_amd.h"
+#include "nbl_desc.h"
+
+extern "C" int nbl_launch_kernel(uint32_t kernel, uint32_t es, const nbl::KArgs* args, void* stream);
+
+namespace {
+
+using namespace nbl;
+
+thread_local std::string g_last_error;
+
+struct PlanError {
+  nbl_status status;
+  std::string msg;
+};
+
+[[noreturn]] void fail(nbl_status st, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  throw PlanError{st, buf};
+}
+#define NBL_CHECK(cond, ...)                         \
+  do {                                               \
+    if (!(cond)) fail(NBL_ERR_CORRUPT, __VA_ARGS__); \
+  } while (0)
+
+// EncodingType / DataType (dwio/nimble/common/Types.h:69-183)
+enum : uint8_t {
+  ET_TRIVIAL = 0, ET_RLE = 1, ET_DICTIONARY = 2, ET_FIXEDBITWIDTH = 3, ET_SENTINEL = 4,
+  ET_NULLABLE = 5, ET_SPARSEBOOL = 6, ET_VARINT = 7, ET_DELTA = 8, ET_CONSTANT = 9,
+  ET_MAINLYCONSTANT = 10, ET_MAX_KNOWN = 22
+};
+enum : uint8_t {
+  DT_UNDEFINED = 0, DT_INT8 = 1, DT_UINT8 = 2, DT_INT16 = 3, DT_UINT16 = 4, DT_INT32 = 5,
+  DT_UINT32 = 6, DT_INT64 = 7, DT_UINT64 = 8, DT_FLOAT = 9, DT_DOUBLE = 10, DT_BOOL = 11,
+  DT_STRING = 12
+};
+
+constexpr uint64_t kAlign = 256;
+constexpr uint64_t kArenaSlop = 64;
+inline uint64_t align_up(uint64_t v, uint64_t a) { return (v + a - 1) / a * a; }
+inline uint32_t div_up32(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+// One encoding of a cascade tree.
+struct PNode {
+  uint8_t enc = 0, dtype = 0;
+  uint8_t es = 0;          // element bytes of the materialised form: numeric size, string 8, bool 0
+  bool is_bool = false, is_string = false;
+  uint32_t rows = 0;
+  uint64_t off = 0, size = 0;  // span of the encoding in the arena
+  int child[2] = {-1, -1};
+  int chunk = -1;
+  int depth = 0;
+  // leaf parameters
+  uint64_t payload_off = 0;  // packed bits / raw values / bitmap / varint bytes / string blob
+  uint64_t payload_bytes = 0;
+  uint64_t value = 0;        // baseline, constant, common value (strings: view)
+  uint8_t width = 0;
+  uint8_t flag = 0;          // sparse value / first bool
+  // string constants (Constant<string>, MainlyConstant<string> common value)
+  uint64_t str_off = 0;      // arena offset of the string bytes
+  uint32_t str_len = 0;
+  // result
+  ColRef ref{};              // how a consumer reads this node
+  int ready = 0;             // level after which `ref` is valid
+};
+
+struct Step {
+  int level;
+  uint32_t kernel;
+  uint32_t es;
+  uint32_t dnode;
+  uint32_t n_tiles;
+  bool per_node;  // K_SCAN_TILES: one workgroup, tile index unused
+};
+
+struct Launch {
+  uint32_t kernel, es;
+  uint32_t tile_begin, n_tiles;
+};
+
+const char* kKernelNames[K_COUNT] = {
+    "k_materialize", "k_bits_to_bytes", "k_reduce_sum", "k_reduce_popc", "k_reduce_varint",
+    "k_scan_tiles", "k_rle_ends", "k_rle_expand", "k_rle_expand_bool", "k_sparse_bits",
+    "k_select_scatter", "k_dict_gather", "k_varint_decode", "k_string_views", "k_copy_bytes",
+    "k_select_bits"};
+
+}  // namespace
+
+struct nbl_plan {
+  const uint8_t* base = nullptr;
+  bool varint_rows = false;
+  uint64_t span = 0;
+  std::vector<PNode> nodes;
+  std::vector<int> roots;
+  std::vector<nbl_chunk_layout> layouts;
+  std::vector<NodeDesc> dnodes;
+  std::vector<uint8_t> aux_in_work;       // per dnode: aux_off is an offset into work (run ends)
+  std::vector<uint32_t> chunk_copies;     // dnodes of the string copies of the chunk being planned
+  std::vector<Step> steps;
+  std::vector<Launch> launches;
+  std::vector<TileRef> tiles;
+  std::vector<uint8_t> blob;  // NodeDesc[] | TileRef[] image uploaded to work
+  uint64_t tiles_off = 0;
+  uint64_t ctrl_off = 0, ctrl_bytes = 0;   // status word + per-node totals (zeroed per decode)
+  uint64_t parts_off = 0;
+  uint32_t n_parts = 0, n_totals = 0;
+  uint64_t out_bytes = 0, work_bytes = 0, desc_bytes = 0;
+  uint64_t cur_out = 0, cur_work = 0;      // allocation cursors
+  uint64_t cur_str = 0;                    // string bytes of the chunk being planned
+  uint64_t str_base = 0;                   // out offset of that chunk's string region
+  uint64_t encoded_bytes = 0, decoded_bytes = 0, total_rows = 0;
+  uint32_t max_depth = 0;
+
+  // ---- parsing ----------------------------------------------------------
+  uint8_t u8(uint64_t o) const { return base[o]; }
+  uint32_t u32(uint64_t o) const { uint32_t v; memcpy(&v, base + o, 4); return v; }
+  uint64_t le(uint64_t o, int n) const { uint64_t v = 0; memcpy(&v, base + o, (size_t)n); return v; }
+
+  int parse(uint64_t off, uint64_t size, int chunk, int depth);
+  void parse_value(PNode& n, uint64_t& pos, uint64_t end);
+  // ---- layout / scheduling ----------------------------------------------
+  uint64_t alloc_work(uint64_t bytes) { uint64_t o = cur_work; cur_work = align_up(cur_work + bytes, kAlign); return o; }
+  uint64_t alloc_out(uint64_t bytes) { uint64_t o = cur_out; cur_out = align_up(cur_out + bytes, kAlign); return o; }
+  uint32_t add_dnode(const NodeDesc& d, bool aux_work = false) {
+    dnodes.push_back(d);
+    aux_in_work.push_back(aux_work ? 1 : 0);
+    return (uint32_t)dnodes.size() - 1;
+  }
+  void add_step(int level, uint32_t kernel, uint32_t es, uint32_t dnode, uint32_t n_tiles, bool per_node = false) {
+    if (n_tiles == 0) return;
+    steps.push_back(Step{level, kernel, es, dnode, n_tiles, per_node});
+  }
+  void alloc_scan(NodeDesc& d, uint32_t n_tiles) {
+    d.part_base = n_parts; d.n_parts = n_tiles; n_parts += n_tiles;
+    d.total_idx = n_totals; n_totals += 2;
+  }
+  uint64_t string_copy(int level, uint64_t arena_off, uint64_t bytes);
+  void place(int idx, bool root, const ColRef* root_dst);
+  void plan_chunk(uint32_t c, uint64_t off, uint64_t size);
+  void finish();
+};
+
+namespace {
+
+int elem_size(uint8_t dt) {
+  switch (dt) {
+    case DT_INT8: case DT_UINT8: return 1;
+    case DT_INT16: case DT_UINT16: return 2;
+    case DT_INT32: case DT_UINT32: case DT_FLOAT: return 4;
+    case DT_INT64: case DT_UINT64: case DT_DOUBLE: return 8;
+    default: return 0;
+  }
+}
+bool is_u32_index_type(uint8_t dt) { return dt == DT_UINT32 || dt == DT_INT32; }
+
+}  // namespace
+
+// Reads the constant / common value that trails an encoding (encoding::read<physicalType>,
+// dwio/nimble/encodings/common/EncodingPrimitives.h:123-160).
+void nbl_plan::parse_value(PNode& n, uint64_t& pos, uint64_t end) {
+  if (n.is_string) {
+    NBL_CHECK(pos + 4 <= end, "string value beyond end of encoding");
+    const uint32_t len = u32(pos);
+    NBL_CHECK(pos + 4 + (uint64_t)len <= end, "string value beyond end of encoding");
+    n.str_off = pos + 4;
+    n.str_len = len;
+    pos += 4 + (uint64_t)len;
+  } else if (n.is_bool) {
+    NBL_CHECK(pos + 1 <= end, "value beyond end of encoding");
+    n.value = u8(pos) != 0;
+    pos += 1;
+  } else {
+    NBL_CHECK(pos + n.es <= end, "value beyond end of encoding");
+    n.value = le(pos, n.es);
+    pos += n.es;
+  }
+}
+
+int nbl_plan::parse(uint64_t off, uint64_t size, int chunk, int depth) {
+  NBL_CHECK(size >= 2, "encoding shorter than its prefix");
+  NBL_CHECK(depth < 32, "cascade deeper than 32 levels");
+  PNode n;
+  n.off = off; n.size = size; n.chunk = chunk; n.depth = depth;
+  n.enc = u8(off);
+  n.dtype = u8(off + 1);
+  uint64_t pos;  // first byte after the prefix
+  if (varint_rows) {  // EncodingPrefix.h:77-92, Varint.h:83-102
+    uint32_t v = 0; pos = off + 2; bool done = false;
+    for (int k = 0; k < 5 && !done; ++k) {
+      NBL_CHECK(pos < off + size, "row count varint beyond end of encoding");
+      const uint8_t b = u8(pos++);
+      v |= (uint32_t)(b & 127) << (7 * k);
+      done = !(b & 128) || k == 4;
+    }
+    n.rows = v;
+  } else {
+    NBL_CHECK(size >= 6, "encoding shorter than its prefix");
+    n.rows = u32(off + 2);
+    pos = off + 6;
+  }
+  const uint64_t end = off + size;
+  if (n.enc > ET_MAX_KNOWN || n.enc == ET_SENTINEL)
+    fail(NBL_ERR_CORRUPT, "Trying to deserialize invalid EncodingType:%d -- garbage input?", (int)n.enc);
+  NBL_CHECK(n.dtype >= DT_INT8 && n.dtype <= DT_STRING, "invalid DataType %d", (int)n.dtype);
+  n.is_bool = n.dtype == DT_BOOL;
+  n.is_string = n.dtype == DT_STRING;
+  n.es = n.is_string ? 8 : (uint8_t)elem_size(n.dtype);
+  max_depth = std::max<uint32_t>(max_depth, (uint32_t)depth + 1);
+
+  const int self = (int)nodes.size();
+  nodes.push_back(n);
+  auto N = [&]() -> PNode& { return nodes[self]; };
+  auto child = [&](int slot, uint64_t coff, uint64_t csize) {
+    NBL_CHECK(coff <= end && csize <= end - coff, "child encoding beyond end of its parent");
+    const int c = parse(coff, csize, chunk, depth + 1);
+    N().child[slot] = c;
+    return c;
+  };
+
+  switch (n.enc) {
+    case ET_TRIVIAL: {  // TrivialEncoding.h:252-283, TrivialEncoding.cpp:33-44,101-136,291-319
+      NBL_CHECK(pos + 1 <= end, "Trivial header beyond end");
+      if (u8(pos) != 0) fail(NBL_ERR_UNSUPPORTED, "compressed Trivial payload (CompressionType %d)", (int)u8(pos));
+      pos += 1;
+      if (n.is_string) {
+        NBL_CHECK(pos + 4 <= end, "Trivial<string> header beyond end");
+        const uint32_t lsize = u32(pos);
+        pos += 4;
+        const int c = child(0, pos, lsize);
+        NBL_CHECK(is_u32_index_type(nodes[c].dtype), "Trivial<string> lengths must be uint32");
+        NBL_CHECK(nodes[c].rows >= N().rows, "Trivial<string> has fewer lengths than rows");
+        pos += lsize;
+        N().payload_off = pos;
+        N().payload_bytes = end - pos;
+      } else if (n.is_bool) {
+        N().payload_off = pos;
+        N().payload_bytes = ((uint64_t)n.rows + 7) / 8;
+        NBL_CHECK(pos + N().payload_bytes + 7 == end, "Unexpected trivial encoding end");
+      } else {
+        N().payload_off = pos;
+        N().payload_bytes = (uint64_t)n.rows * n.es;
+        NBL_CHECK(pos + N().payload_bytes == end, "Unexpected trivial encoding end");
+      }
+      break;
+    }
+    case ET_FIXEDBITWIDTH: {  // FixedBitWidthEncoding.h:149-175
+      NBL_CHECK(!n.is_bool && !n.is_string, "FixedBitWidth needs a numeric data type");
+      NBL_CHECK(pos + 2 + n.es <= end, "FixedBitWidth header beyond end");
+      if (u8(pos) != 0) fail(NBL_ERR_UNSUPPORTED, "compressed FixedBitWidth payload (CompressionType %d)", (int)u8(pos));
+      N().value = le(pos + 1, n.es);
+      N().width = u8(pos + 1 + n.es);
+      pos += 2 + n.es;
+      NBL_CHECK(N().width <= 64, "bit width must lie in [0, 64], got: %d", (int)N().width);
+      NBL_CHECK(n.es == 8 || N().width <= 32, "bit width must lie in [1, 32], got: %d", (int)N().width);
+      N().payload_off = pos;
+      N().payload_bytes = ((uint64_t)n.rows * N().width + 7) / 8;
+      // FixedBitArray::bufferSize: packed bytes + 7 bytes the word loads may touch
+      NBL_CHECK(n.rows == 0 || pos + N().payload_bytes + 7 <= end, "FixedBitWidth payload truncated");
+      break;
+    }
+    case ET_VARINT: {  // VarintEncoding.h:94-111
+      NBL_CHECK(!n.is_bool && !n.is_string && (n.es == 4 || n.es == 8), "Varint needs a 4- or 8-byte numeric type");
+      NBL_CHECK(pos + n.es <= end, "Varint header beyond end");
+      N().value = le(pos, n.es);
+      pos += n.es;
+      N().payload_off = pos;
+      N().payload_bytes = end - pos;
+      NBL_CHECK(N().payload_bytes >= n.rows, "Varint payload truncated");
+      break;
+    }
+    case ET_CONSTANT: {  // ConstantEncoding.h:292-302, ConstantEncoding.cpp:21-33
+      parse_value(N(), pos, end);
+      NBL_CHECK(pos == end, "Unexpected constant encoding end");
+      break;
+    }
+    case ET_RLE: {  // RLEEncoding.h:113-124,816-837, RLEEncoding.cpp:20-37
+      NBL_CHECK(pos + 4 <= end, "RLE header beyond end");
+      const uint32_t lsize = u32(pos);
+      pos += 4;
+      const int c0 = child(0, pos, lsize);
+      NBL_CHECK(is_u32_index_type(nodes[c0].dtype), "RLE run lengths must be uint32");
+      pos += lsize;
+      if (n.is_bool) {
+        NBL_CHECK(pos + 1 == end, "Unexpected run length encoding end");
+        N().flag = u8(pos) != 0;
+      } else {
+        NBL_CHECK(pos < end, "RLE run values missing");
+        const int c1 = child(1, pos, end - pos);
+        NBL_CHECK(nodes[c1].dtype == n.dtype, "RLE run values have a different data type");
+        NBL_CHECK(nodes[c1].rows >= nodes[c0].rows, "RLE has fewer run values than run lengths");
+      }
+      break;
+    }
+    case ET_DICTIONARY: {  // DictionaryEncoding.h:193-214
+      NBL_CHECK(!n.is_bool, "Dictionary does not support bool");
+      NBL_CHECK(pos + 4 <= end, "Dictionary header beyond end");
+      const uint32_t asize = u32(pos);
+      pos += 4;
+      const int c0 = child(0, pos, asize);
+      NBL_CHECK(nodes[c0].dtype == n.dtype, "Dictionary alphabet has a different data type");
+      pos += asize;
+      NBL_CHECK(pos < end, "Dictionary indices missing");
+      const int c1 = child(1, pos, end - pos);
+      NBL_CHECK(is_u32_index_type(nodes[c1].dtype), "Dictionary indices must be uint32");
+      NBL_CHECK(nodes[c1].rows >= N().rows, "Dictionary has fewer indices than rows");
+      break;
+    }
+    case ET_NULLABLE: {  // NullableEncoding.h:151-171
+      NBL_CHECK(pos + 4 <= end, "Nullable header beyond end");
+      const uint32_t dsize = u32(pos);
+      pos += 4;
+      const int c0 = child(0, pos, dsize);
+      NBL_CHECK(nodes[c0].dtype == n.dtype, "Nullable data has a different data type");
+      pos += dsize;
+      NBL_CHECK(pos < end, "Nullable nulls missing");
+      const int c1 = child(1, pos, end - pos);
+      NBL_CHECK(nodes[c1].dtype == DT_BOOL, "Nullable nulls must be bool");
+      NBL_CHECK(nodes[c1].rows == N().rows, "Nulls count mismatch.");
+      NBL_CHECK(nodes[c0].rows <= N().rows, "Nullable has more non-null values than rows");
+      break;
+    }
+    case ET_SPARSEBOOL: {  // SparseBoolEncoding.cpp:70-84, EncodingFactory.cpp:90-97
+      NBL_CHECK(n.is_bool, "Trying to deserialize a SparseBoolEncoding with a non-bool data type.");
+      NBL_CHECK(pos + 1 < end, "SparseBool header beyond end");
+      N().flag = u8(pos) != 0;
+      pos += 1;
+      const int c0 = child(0, pos, end - pos);
+      NBL_CHECK(is_u32_index_type(nodes[c0].dtype), "SparseBool indices must be uint32");
+      NBL_CHECK(nodes[c0].rows >= 1, "SparseBool indices lack the row-count sentinel");
+      break;
+    }
+    case ET_MAINLYCONSTANT: {  // MainlyConstantEncoding.h:842-860, MainlyConstantEncoding.cpp:21-43
+      NBL_CHECK(!n.is_bool, "MainlyConstant does not support bool");
+      NBL_CHECK(pos + 4 <= end, "MainlyConstant header beyond end");
+      const uint32_t isize = u32(pos);
+      pos += 4;
+      const int c0 = child(0, pos, isize);
+      NBL_CHECK(nodes[c0].dtype == DT_BOOL && nodes[c0].rows == N().rows, "MainlyConstant isCommon mismatch");
+      pos += isize;
+      NBL_CHECK(pos + 4 <= end, "MainlyConstant header beyond end");
+      const uint32_t osize = u32(pos);
+      pos += 4;
+      const int c1 = child(1, pos, osize);
+      NBL_CHECK(nodes[c1].dtype == n.dtype, "MainlyConstant other values have a different data type");
+      NBL_CHECK(nodes[c1].rows <= N().rows, "MainlyConstant has more other values than rows");
+      pos += osize;
+      parse_value(N(), pos, end);
+      NBL_CHECK(pos == end, "Unexpected mainly constant encoding end");
+      break;
+    }
+    default:
+      // Delta, Prefix, ALP, PFOR, ... : valid Nimble, decoded by the CPU factory.
+      fail(NBL_ERR_UNSUPPORTED, "EncodingType %d is not decoded on the GPU", (int)n.enc);
+  }
+  return self;
+}
+
+// Registers a copy of `bytes` string bytes from the arena into the chunk's
+// string region; returns the offset of the copy relative to that region.
+uint64_t nbl_plan::string_copy(int level, uint64_t arena_off, uint64_t bytes) {
+  const uint64_t rel = cur_str;
+  cur_str = align_up(cur_str + bytes, 16);
+  if (bytes) {
+    NodeDesc d{};
+    d.self.kind = COL_MAT_OUT;
+    d.self.off = rel;        // plan_chunk adds the region's offset once it is known
+    d.aux = bytes;
+    d.aux_off = arena_off;
+    const uint32_t dn = add_dnode(d);
+    chunk_copies.push_back(dn);
+    add_step(level, K_COPY_BYTES, 1, dn, div_up32(bytes, kTileBytes));
+    decoded_bytes += bytes;
+  }
+  return rel;
+}
+
+// Decides how node `idx` is produced and schedules its kernels.  `root_dst`
+// (roots only) is where the values go in `out`.
+void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
+  PNode& nn = nodes[idx];  // `nodes` no longer grows once parsing is done
+  const uint32_t rows = nn.rows;
+  // children first
+  for (int s = 0; s < 2; ++s)
+    if (nn.child[s] >= 0) place(nn.child[s], false, nullptr);
+  auto C = [&](int s) -> PNode& { return nodes[nn.child[s]]; };
+  int lvl = 0;
+  for (int s = 0; s < 2; ++s)
+    if (nn.child[s] >= 0) lvl = std::max(lvl, C(s).ready);
+
+  auto mat_ref = [&](uint32_t es) {  // destination of a materialised numeric / view column
+    ColRef r{};
+    if (root && !nn.is_bool) { r = *root_dst; }
+    else { r.kind = COL_MAT_WORK; r.off = alloc_work((uint64_t)rows * es); }
+    r.rows = rows; r.es = (uint8_t)es;
+    return r;
+  };
+  auto bits_ref = [&]() {
+    ColRef r{};
+    r.kind = COL_BITS_WORK; r.off = alloc_work(((uint64_t)rows + 63) / 64 * 8); r.rows = rows; r.es = 0;
+    return r;
+  };
+  const uint32_t es = nn.es;
+  const uint32_t tile_rows = es ? kTileBytes / es : kBitTileRows;
+
+  switch (nn.enc) {
+    case ET_FIXEDBITWIDTH: {
+      ColRef r{};
+      if (nn.width == 0) { r.kind = COL_CONST; r.base = nn.value; }
+      else { r.kind = COL_FBW; r.off = nn.payload_off; r.base = nn.value; r.width = nn.width; }
+      r.rows = rows; r.es = (uint8_t)es;
+      nn.ref = r; nn.ready = 0;
+      break;
+    }
+    case ET_TRIVIAL: {
+      if (nn.is_string) {
+        // views = running sum of the lengths; blob copied to the string region
+        const uint64_t rel = string_copy(0, nn.payload_off, nn.payload_bytes);
+        NodeDesc d{};
+        d.self = mat_ref(8);
+        d.c0 = C(0).ref; d.c0.rows = std::min(d.c0.rows, C(0).rows);
+        d.rows = rows; d.aux = rel; d.aux2 = nn.payload_bytes;
+        const uint32_t nt = div_up32(rows, kScanTile);
+        alloc_scan(d, nt);
+        const uint32_t dn = add_dnode(d);
+        add_step(lvl, K_REDUCE_SUM, 4, dn, nt);
+        add_step(lvl + 1, K_SCAN_TILES, 0, dn, 1, true);
+        add_step(lvl + 2, K_STRING_VIEWS, 8, dn, nt);
+        nn.ref = d.self; nn.ready = lvl + 3;
+      } else if (nn.is_bool) {
+        ColRef r{}; r.kind = COL_BITS_RAW; r.off = nn.payload_off; r.rows = rows;
+        nn.ref = r; nn.ready = 0;
+      } else {
+        ColRef r{}; r.kind = COL_RAW; r.off = nn.payload_off; r.rows = rows; r.es = (uint8_t)es;
+        nn.ref = r; nn.ready = 0;
+      }
+      break;
+    }
+    case ET_CONSTANT: {
+      ColRef r{}; r.kind = COL_CONST; r.rows = rows; r.es = nn.is_bool ? 0 : (uint8_t)es;
+      if (nn.is_string) {
+        const uint64_t rel = string_copy(0, nn.str_off, nn.str_len);
+        r.base = ((uint64_t)nn.str_len << 32) | (uint32_t)rel;
+      } else {
+        r.base = nn.value;
+      }
+      nn.ref = r; nn.ready = 0;
+      break;
+    }
+    case ET_VARINT: {
+      NodeDesc d{};
+      d.self = mat_ref(es);
+      d.c0.kind = COL_RAW; d.c0.off = nn.payload_off; d.c0.base = nn.value; d.c0.rows = rows; d.c0.es = (uint8_t)es;
+      d.rows = rows; d.aux2 = nn.payload_bytes;
+      const uint32_t nt = div_up32(nn.payload_bytes, kVarintTile);
+      alloc_scan(d, nt);
+      const uint32_t dn = add_dnode(d);
+      add_step(lvl, K_REDUCE_VARINT, 0, dn, nt);
+      add_step(lvl + 1, K_SCAN_TILES, 0, dn, 1, true);
+      add_step(lvl + 2, K_VARINT_DECODE, es, dn, nt);
+      nn.ref = d.self; nn.ready = lvl + 3;
+      break;
+    }
+    case ET_RLE: {
+      NodeDesc d{};
+      d.c0 = C(0).ref;
+      d.rows = rows;
+      const uint32_t R = C(0).rows;
+      d.c0.rows = R;
+      const uint32_t nt = div_up32(R, kScanTile);
+      alloc_scan(d, nt);
+      d.aux_off = alloc_work((uint64_t)R * 4);
+      if (nn.is_bool) {
+        d.self = bits_ref();
+        if (nn.flag) d.flags |= NF_FIRST_TRUE;
+      } else {
+        d.self = mat_ref(es);
+        d.c1 = C(1).ref;
+      }
+      const uint32_t dn = add_dnode(d, /*aux_work=*/true);
+      add_step(lvl, K_REDUCE_SUM, 4, dn, nt);
+      add_step(lvl + 1, K_SCAN_TILES, 0, dn, 1, true);
+      add_step(lvl + 2, K_RLE_ENDS, 4, dn, nt);
+      if (nn.is_bool) add_step(lvl + 3, K_RLE_EXPAND_BOOL, 0, dn, div_up32(rows, kBitTileRows));
+      else add_step(lvl + 3, K_RLE_EXPAND, es, dn, div_up32(rows, tile_rows));
+      nn.ref = d.self; nn.ready = lvl + 4;
+      break;
+    }
+    case ET_SPARSEBOOL: {
+      NodeDesc d{};
+      d.self = bits_ref();
+      d.c0 = C(0).ref;
+      d.rows = rows;
+      if (nn.flag) d.flags |= NF_SPARSE_VALUE;
+      const uint32_t dn = add_dnode(d);
+      add_step(lvl, K_SPARSE_BITS, 0, dn, div_up32(rows, kBitTileRows));
+      nn.ref = d.self; nn.ready = lvl + 1;
+      break;
+    }
+    case ET_DICTIONARY: {
+      NodeDesc d{};
+      d.self = mat_ref(es);
+      d.c0 = C(1).ref;  // indices
+      d.c1 = C(0).ref;  // alphabet
+      d.rows = rows;
+      const uint32_t dn = add_dnode(d);
+      add_step(lvl, K_DICT_GATHER, es, dn, div_up32(rows, tile_rows));
+      nn.ref = d.self; nn.ready = lvl + 1;
+      break;
+    }
+    case ET_NULLABLE:
+    case ET_MAINLYCONSTANT: {
+      const bool nullable = nn.enc == ET_NULLABLE;
+      NodeDesc d{};
+      d.rows = rows;
+      d.sel = nullable ? C(1).ref : C(0).ref;
+      d.sel.rows = rows;
+      d.c1 = nullable ? C(0).ref : C(1).ref;
+      if (!nullable) {
+        d.flags |= NF_INVERT_SEL;
+        if (nn.is_string) {
+          const uint64_t rel = string_copy(0, nn.str_off, nn.str_len);
+          d.aux = ((uint64_t)nn.str_len << 32) | (uint32_t)rel;
+        } else {
+          d.aux = nn.value;
+        }
+      }
+      if (nullable && root) {
+        d.flags |= NF_WRITE_NULLS;
+        d.aux_off = layouts[(size_t)nn.chunk].nulls_offset;
+      }
+      const uint32_t trows = nn.is_bool ? kBitTileRows : tile_rows;
+      d.aux2 = trows;
+      const uint32_t nt = div_up32(rows, trows);
+      alloc_scan(d, nt);
+      d.self = nn.is_bool ? bits_ref() : mat_ref(es);
+      const uint32_t dn = add_dnode(d);
+      add_step(lvl, K_REDUCE_POPC, 0, dn, nt);
+      add_step(lvl + 1, K_SCAN_TILES, 0, dn, 1, true);
+      if (nn.is_bool) add_step(lvl + 2, K_SELECT_BITS, 0, dn, nt);
+      else add_step(lvl + 2, K_SELECT_SCATTER, es, dn, nt);
+      nn.ref = d.self; nn.ready = lvl + 3;
+      break;
+    }
+    default:
+      fail(NBL_ERR_UNSUPPORTED, "EncodingType %d is not decoded on the GPU", (int)nn.enc);
+  }
+
+  if (root) {
+    PNode& r = nodes[idx];
+    if (r.is_bool) {  // bitmap (or constant) -> one byte per row
+      NodeDesc d{};
+      d.self = *root_dst; d.self.rows = rows; d.self.es = 1;
+      d.c0 = r.ref; d.rows = rows;
+      const uint32_t dn = add_dnode(d);
+      add_step(r.ready, K_BITS_TO_BYTES, 1, dn, div_up32(rows, kTileBytes));
+      r.ready += 1;
+    } else if (r.ref.kind != COL_MAT_OUT) {  // leaf root: unpack / copy / fill into out
+      NodeDesc d{};
+      d.self = *root_dst; d.self.rows = rows; d.self.es = (uint8_t)es;
+      d.c0 = r.ref; d.rows = rows;
+      const uint32_t dn = add_dnode(d);
+      add_step(r.ready, K_MATERIALIZE, es, dn, div_up32(rows, tile_rows));
+      r.ready += 1;
+    }
+  }
+}
+
+void nbl_plan::plan_chunk(uint32_t c, uint64_t off, uint64_t size) {
+  chunk_copies.clear();
+  const int root = parse(off, size, (int)c, 0);
+  roots.push_back(root);
+  const PNode r = nodes[root];
+  nbl_chunk_layout& L = layouts[c];
+  memset(&L, 0, sizeof L);
+  L.rows = r.rows; L.encoding_type = r.enc; L.data_type = r.dtype;
+  L.nullable = r.enc == ET_NULLABLE;
+  L.elem_bytes = r.is_bool ? 1 : r.es;
+  L.non_null_rows = L.nullable ? nodes[r.child[0]].rows : r.rows;
+  L.values_bytes = (uint64_t)r.rows * L.elem_bytes;
+  L.values_offset = alloc_out(L.values_bytes);
+  if (L.nullable) {
+    L.nulls_bytes = ((uint64_t)r.rows + 63) / 64 * 8;
+    L.nulls_offset = alloc_out(L.nulls_bytes);
+  }
+  ColRef dst{};
+  dst.kind = COL_MAT_OUT; dst.off = L.values_offset; dst.rows = r.rows; dst.es = L.elem_bytes;
+  cur_str = 0;
+  place(root, true, &dst);
+  if (r.is_string) {
+    L.string_bytes = cur_str;
+    L.string_offset = alloc_out(cur_str);
+    for (uint32_t dn : chunk_copies) dnodes[dn].self.off += L.string_offset;
+  }
+  encoded_bytes += size;
+  decoded_bytes += L.values_bytes + L.nulls_bytes;
+  total_rows += r.rows;
+}
+
+// Orders the steps by level, merges equal (level, kernel, element size) into one
+// launch and lays out the work buffer.
+void nbl_plan::finish() {
+  std::stable_sort(steps.begin(), steps.end(), [](const Step& a, const Step& b) {
+    return std::tie(a.level, a.kernel, a.es) < std::tie(b.level, b.kernel, b.es);
+  });
+  for (size_t i = 0; i < steps.size();) {
+    size_t j = i;
+    Launch L{steps[i].kernel, steps[i].es, (uint32_t)tiles.size(), 0};
+    while (j < steps.size() && steps[j].level == steps[i].level && steps[j].kernel == steps[i].kernel && steps[j].es == steps[i].es) {
+      for (uint32_t t = 0; t < steps[j].n_tiles; ++t) tiles.push_back(TileRef{steps[j].dnode, t});
+      ++j;
+    }
+    L.n_tiles = (uint32_t)tiles.size() - L.tile_begin;
+    launches.push_back(L);
+    i = j;
+  }
+  // work = [NodeDesc[] | TileRef[]] [ctrl] [parts] [intermediates...]
+  const uint64_t nd_bytes = align_up(dnodes.size() * sizeof(NodeDesc), kAlign);
+  const uint64_t tl_bytes = align_up(tiles.size() * sizeof(TileRef), kAlign);
+  tiles_off = nd_bytes;
+  desc_bytes = nd_bytes + tl_bytes;
+  ctrl_off = desc_bytes;
+  ctrl_bytes = align_up(4 + (uint64_t)n_totals * 4, kAlign);
+  parts_off = ctrl_off + ctrl_bytes;
+  const uint64_t scratch_base = align_up(parts_off + (uint64_t)n_parts * 4, kAlign);
+  // intermediates were allocated from a cursor starting at 0: rebase them
+  for (NodeDesc& d : dnodes) {
+    ColRef* refs[4] = {&d.self, &d.c0, &d.c1, &d.sel};
+    for (ColRef* r : refs)
+      if (r->kind == COL_MAT_WORK || r->kind == COL_BITS_WORK) r->off += scratch_base;
+  }
+  for (size_t i = 0; i < dnodes.size(); ++i)
+    if (aux_in_work[i]) dnodes[i].aux_off += scratch_base;  // run-end arrays
+  work_bytes = scratch_base + cur_work + kAlign;
+  out_bytes = std::max<uint64_t>(cur_out, kAlign);
+  blob.assign(desc_bytes, 0);
+  if (!dnodes.empty()) memcpy(blob.data(), dnodes.data(), dnodes.size() * sizeof(NodeDesc));
+  if (!tiles.empty()) memcpy(blob.data() + tiles_off, tiles.data(), tiles.size() * sizeof(TileRef));
+}
+
+// =============================== C ABI =====================================
+extern "C" {
+
+const char* nbl_last_error(void) { return g_last_error.c_str(); }
+const char* nbl_build_arch(void) { return "gfx950"; }
+
+nbl_status nbl_split_stream(const uint8_t* stream, uint64_t size, uint64_t* offsets, uint64_t* sizes,
+                            uint32_t capacity, uint32_t* n_chunks) {
+  if ((!stream && size) || !n_chunks) { g_last_error = "null argument"; return NBL_ERR_ARGUMENT; }
+  uint64_t pos = 0; uint32_t n = 0;
+  while (pos < size) {  // InMemoryChunkedStream::nextChunk, velox/ChunkedStream.cpp:36-72
+    if (size - pos < 5) { g_last_error = "Read beyond end of stream"; return NBL_ERR_CORRUPT; }
+    uint32_t len; memcpy(&len, stream + pos, 4);
+    const uint8_t comp = stream[pos + 4];
+    pos += 5;
+    if (len > size - pos) { g_last_error = "Read beyond end of stream"; return NBL_ERR_CORRUPT; }
+    if (comp == 1 || comp == 3) { g_last_error = "compressed chunk (Zstd/Lz4): decompress on the host first"; return NBL_ERR_UNSUPPORTED; }
+    if (comp != 0) { g_last_error = "Unexpected stream compression type: " + std::to_string((int)comp); return NBL_ERR_CORRUPT; }
+    if (n < capacity && offsets && sizes) { offsets[n] = pos; sizes[n] = len; }
+    ++n; pos += len;
+  }
+  *n_chunks = n;
+  return NBL_OK;
+}
+
+nbl_status nbl_plan_batch(const uint8_t* base, const uint64_t* offsets, const uint64_t* sizes, uint32_t n_chunks,
+                          const nbl_options* options, nbl_plan** plan_out) {
+  if (!plan_out || (n_chunks && (!base || !offsets || !sizes))) { g_last_error = "null argument"; return NBL_ERR_ARGUMENT; }
+  *plan_out = nullptr;
+  nbl_plan* p = new nbl_plan();
+  try {
+    p->base = base;
+    p->varint_rows = options && options->struct_size >= sizeof(nbl_options) && options->use_varint_row_count;
+    p->layouts.resize(n_chunks);
+    for (uint32_t c = 0; c < n_chunks; ++c) p->span = std::max(p->span, offsets[c] + sizes[c]);
+    for (uint32_t c = 0; c < n_chunks; ++c) p->plan_chunk(c, offsets[c], sizes[c]);
+    p->finish();
+    p->base = nullptr;  // the host bytes are not needed after planning
+  } catch (const PlanError& e) {
+    g_last_error = e.msg;
+    delete p;
+    return e.status;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    delete p;
+    return NBL_ERR_ARGUMENT;
+  }
+  *plan_out = p;
+  return NBL_OK;
+}
+
+void nbl_plan_free(nbl_plan* plan) { delete plan; }
+
+nbl_status nbl_plan_get_info(const nbl_plan* p, nbl_plan_info* info) {
+  if (!p || !info) { g_last_error = "null argument"; return NBL_ERR_ARGUMENT; }
+  memset(info, 0, sizeof *info);
+  info->n_chunks = (uint32_t)p->layouts.size();
+  info->n_nodes = (uint32_t)p->nodes.size();
+  info->n_launches = (uint32_t)p->launches.size();
+  info->max_depth = p->max_depth;
+  info->arena_bytes = p->span + kArenaSlop;
+  info->out_bytes = p->out_bytes;
+  info->work_bytes = p->work_bytes;
+  info->descriptor_bytes = p->desc_bytes;
+  info->total_rows = p->total_rows;
+  info->encoded_bytes = p->encoded_bytes;
+  info->decoded_bytes = p->decoded_bytes;
+  return NBL_OK;
+}
+
+nbl_status nbl_plan_get_chunk_layout(const nbl_plan* p, uint32_t chunk, nbl_chunk_layout* layout) {
+  if (!p || !layout || chunk >= p->layouts.size()) { g_last_error = "bad chunk index"; return NBL_ERR_ARGUMENT; }
+  *layout = p->layouts[chunk];
+  return NBL_OK;
+}
+
+nbl_status nbl_plan_get_launch(const nbl_plan* p, uint32_t launch, const char** kernel_name, uint32_t* n_tiles) {
+  if (!p || launch >= p->launches.size()) { g_last_error = "bad launch index"; return NBL_ERR_ARGUMENT; }
+  if (kernel_name) *kernel_name = kKernelNames[p->launches[launch].kernel];
+  if (n_tiles) *n_tiles = p->launches[launch].n_tiles;
+  return NBL_OK;
+}
+
+static nbl_status hip_fail(const char* what, hipError_t e) {
+  g_last_error = std::string(what) + ": " + hipGetErrorString(e);
+  return NBL_ERR_HIP;
+}
+
+nbl_status nbl_plan_upload(nbl_plan* p, void* d_work, void* stream) {
+  if (!p || !d_work) { g_last_error = "null argument"; return NBL_ERR_ARGUMENT; }
+  if (p->blob.empty()) return NBL_OK;
+  hipError_t e = hipMemcpyAsync(d_work, p->blob.data(), p->blob.size(), hipMemcpyHostToDevice, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail("hipMemcpyAsync(descriptors)", e);
+  return NBL_OK;
+}
+
+nbl_status nbl_decode_batch_device(const nbl_plan* p, const void* d_arena, void* d_out, void* d_work, void* stream) {
+  if (!p || !d_work || (!d_arena && p->span) || !d_out) { g_last_error = "null argument"; return NBL_ERR_ARGUMENT; }
+  uint8_t* work = static_cast<uint8_t*>(d_work);
+  hipError_t e = hipMemsetAsync(work + p->ctrl_off, 0, p->ctrl_bytes, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail("hipMemsetAsync(control words)", e);
+  KArgs a{};
+  a.arena = static_cast<const uint8_t*>(d_arena);
+  a.out = static_cast<uint8_t*>(d_out);
+  a.work = work;
+  a.nodes = reinterpret_cast<const NodeDesc*>(work);
+  a.status = reinterpret_cast<uint32_t*>(work + p->ctrl_off);
+  a.totals = a.status + 1;
+  a.parts = reinterpret_cast<uint32_t*>(work + p->parts_off);
+  const TileRef* tiles = reinterpret_cast<const TileRef*>(work + p->tiles_off);
+  for (const Launch& L : p->launches) {
+    a.tiles = tiles + L.tile_begin;
+    a.n_tiles = L.n_tiles;
+    const int rc = nbl_launch_kernel(L.kernel, L.es, &a, stream);
+    if (rc != 0) {
+      g_last_error = std::string("launch of ") + kKernelNames[L.kernel] + " failed";
+      return NBL_ERR_HIP;
+    }
+  }
+  return NBL_OK;
+}
+
+nbl_status nbl_decode_status(const nbl_plan* p, const void* d_work, void* stream) {
+  if (!p || !d_work) { g_last_error = "null argument"; return NBL_ERR_ARGUMENT; }
+  uint32_t st = 0;
+  hipError_t e = hipMemcpyAsync(&st, static_cast<const uint8_t*>(d_work) + p->ctrl_off, 4, hipMemcpyDeviceToHost,
+                                static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail("hipMemcpyAsync(status)", e);
+  e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail("hipStreamSynchronize", e);
+  if (st == 0) return NBL_OK;
+  std::string m = "inconsistent payload:";
+  if (st & ST_RLE_SUM_MISMATCH) m += " run lengths do not add up to the row count;";
+  if (st & ST_DICT_INDEX_RANGE) m += " dictionary index out of range;";
+  if (st & ST_SELECT_COUNT) m += " selected-row count differs from the values child;";
+  if (st & ST_VARINT_COUNT) m += " fewer varints than rows;";
+  if (st & ST_STRING_BYTES) m += " string lengths exceed the blob;";
+  g_last_error = m;
+  return NBL_ERR_DEVICE_DATA;
+}
+
+}  // extern "C"

@@ -1,0 +1,174 @@
+"""Python harness over the C ABI: plan a batch of chunks, stage it on the GPU,
+decode, fetch results.  PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import capi
+from . import wire as W
+
+
+@dataclass
+class ChunkResult:
+    """Decoded output of one chunk, as the reference's Encoding::materialize /
+    materializeNullable define it (null rows hold zero / an empty string)."""
+
+    rows: int
+    data_type: int
+    non_null: int
+    values: object  # numeric: ndarray of the physical type; bool: uint8 0/1;
+    #                 string: (lengths uint32[rows], blob uint8[...]) in row order
+    nulls: Optional[np.ndarray]  # bitmap bytes (1 = non-null), None when the chunk is not Nullable
+    views: Optional[np.ndarray] = None  # string: raw {offset,len} pairs as uint64
+    string_bytes: Optional[np.ndarray] = None  # string: the chunk's string region
+
+
+class Plan:
+    """nbl_plan_batch over chunks stored in one host buffer."""
+
+    def __init__(self, buffer, chunks: Sequence[tuple[int, int]], varint_rows: bool = False):
+        self.buffer = capi.as_u8(buffer)
+        self.chunks = [(int(o), int(s)) for o, s in chunks]
+        n = len(self.chunks)
+        offs = np.array([c[0] for c in self.chunks], dtype=np.uint64)
+        sizes = np.array([c[1] for c in self.chunks], dtype=np.uint64)
+        for o, s in self.chunks:
+            if o + s > self.buffer.size:
+                raise ValueError("chunk outside the buffer")
+        opts = capi.NblOptions(C.sizeof(capi.NblOptions), int(varint_rows))
+        handle = C.c_void_p()
+        capi.check(capi.lib().nbl_plan_batch(self.buffer.ctypes.data, offs.ctypes.data, sizes.ctypes.data, n,
+                                             C.byref(opts), C.byref(handle)))
+        self._h = handle
+        info = capi.NblPlanInfo()
+        capi.check(capi.lib().nbl_plan_get_info(self._h, C.byref(info)))
+        self.info = info
+        self.layouts = []
+        for i in range(n):
+            lay = capi.NblChunkLayout()
+            capi.check(capi.lib().nbl_plan_get_chunk_layout(self._h, i, C.byref(lay)))
+            self.layouts.append(lay)
+
+    @staticmethod
+    def from_encodings(encodings: Sequence[bytes], varint_rows: bool = False) -> "Plan":
+        """Concatenates standalone encodings (16-byte aligned starts are NOT
+        required; they are packed back to back on purpose)."""
+        offs, pos = [], 0
+        for e in encodings:
+            offs.append((pos, len(e)))
+            pos += len(e)
+        buf = np.frombuffer(b"".join(bytes(e) for e in encodings), dtype=np.uint8) if encodings else np.zeros(0, np.uint8)
+        return Plan(buf, offs, varint_rows)
+
+    def launches(self):
+        out = []
+        for i in range(self.info.n_launches):
+            name = C.c_char_p()
+            nt = C.c_uint32()
+            capi.check(capi.lib().nbl_plan_get_launch(self._h, i, C.byref(name), C.byref(nt)))
+            out.append((name.value.decode(), nt.value))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            capi.lib().nbl_plan_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class BatchDecoder:
+    """Device buffers + decode for one Plan (one GPU, one stream)."""
+
+    def __init__(self, plan: Plan, device: str = "cuda:0", stream=None):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("BatchDecoder needs a GPU (there is no CPU fallback)")
+        self.torch = torch
+        self.plan = plan
+        self.device = torch.device(device)
+        info = plan.info
+        with torch.cuda.device(self.device):
+            self.arena = torch.zeros(int(info.arena_bytes), dtype=torch.uint8, device=self.device)
+            self.out = torch.zeros(int(info.out_bytes), dtype=torch.uint8, device=self.device)
+            self.work = torch.zeros(int(info.work_bytes), dtype=torch.uint8, device=self.device)
+        self.stream = stream
+        self._uploaded = False
+
+    def _stream_ptr(self):
+        s = self.stream if self.stream is not None else self.torch.cuda.current_stream(self.device)
+        return C.c_void_p(s.cuda_stream)
+
+    def stage(self):
+        """H2D of the encoded bytes and of the plan's descriptor tables."""
+        torch = self.torch
+        host = torch.from_numpy(self.plan.buffer.copy() if not self.plan.buffer.flags.writeable else self.plan.buffer)
+        with torch.cuda.device(self.device):
+            self.arena[: host.numel()].copy_(host, non_blocking=False)
+            capi.check(capi.lib().nbl_plan_upload(self.plan._h, C.c_void_p(self.work.data_ptr()), self._stream_ptr()))
+        self._uploaded = True
+
+    def decode(self):
+        """Asynchronous: enqueues every cascade level on the stream."""
+        if not self._uploaded:
+            self.stage()
+        with self.torch.cuda.device(self.device):
+            capi.check(capi.lib().nbl_decode_batch_device(
+                self.plan._h, C.c_void_p(self.arena.data_ptr()), C.c_void_p(self.out.data_ptr()),
+                C.c_void_p(self.work.data_ptr()), self._stream_ptr()))
+
+    def status(self):
+        with self.torch.cuda.device(self.device):
+            capi.check(capi.lib().nbl_decode_status(self.plan._h, C.c_void_p(self.work.data_ptr()), self._stream_ptr()))
+
+    def fetch(self) -> list[ChunkResult]:
+        """D2H of the outputs, split per chunk."""
+        self.torch.cuda.synchronize(self.device)
+        host = self.out.cpu().numpy()
+        return [slice_chunk(host, lay) for lay in self.plan.layouts]
+
+
+def slice_chunk(host_out: np.ndarray, lay) -> ChunkResult:
+    rows = int(lay.rows)
+    vals = host_out[int(lay.values_offset): int(lay.values_offset) + int(lay.values_bytes)]
+    nulls = None
+    if lay.nullable:
+        nulls = host_out[int(lay.nulls_offset): int(lay.nulls_offset) + (rows + 7) // 8].copy()
+    if lay.data_type == W.STRING:
+        views = vals.view(np.uint64).copy()
+        region = host_out[int(lay.string_offset): int(lay.string_offset) + int(lay.string_bytes)]
+        lengths = (views >> np.uint64(32)).astype(np.uint32)
+        offs = (views & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        total = int(lengths.sum(dtype=np.uint64))
+        if total:
+            row_of = np.repeat(np.arange(rows, dtype=np.int64), lengths.astype(np.int64))
+            starts = np.zeros(rows + 1, dtype=np.int64)
+            np.cumsum(lengths, dtype=np.int64, out=starts[1:])
+            src = offs[row_of] + (np.arange(total, dtype=np.int64) - starts[row_of])
+            blob = region[src]
+        else:
+            blob = np.zeros(0, dtype=np.uint8)
+        return ChunkResult(rows, int(lay.data_type), int(lay.non_null_rows), (lengths, blob), nulls, views, region.copy())
+    if lay.data_type == W.BOOL:
+        return ChunkResult(rows, int(lay.data_type), int(lay.non_null_rows), vals.copy(), nulls)
+    return ChunkResult(rows, int(lay.data_type), int(lay.non_null_rows),
+                       vals.view(W.physical_dtype(lay.data_type)).copy(), nulls)
+
+
+def decode_encodings(encodings: Sequence[bytes], varint_rows: bool = False, device: str = "cuda:0") -> list[ChunkResult]:
+    """Convenience: plan + stage + decode + status + fetch for standalone encodings."""
+    plan = Plan.from_encodings(encodings, varint_rows)
+    dec = BatchDecoder(plan, device)
+    dec.stage()
+    dec.decode()
+    dec.status()
+    res = dec.fetch()
+    plan.close()
+    return res

@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def gpu():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import nimble_amd.capi as capi
+
+    capi.lib()  # the HIP library must be present: there is no CPU fallback
+    return torch.device("cuda:0")
