@@ -150,10 +150,37 @@ nbl_status nbl_decode_batch_device(const nbl_plan* plan, const void* d_arena,
  * out of range): NBL_OK or NBL_ERR_DEVICE_DATA. */
 nbl_status nbl_decode_status(const nbl_plan* plan, const void* d_work, void* stream);
 
-/* Number of launches and, for launch i, the kernel name and tile count (for
- * profiling and roofline accounting). */
-nbl_status nbl_plan_get_launch(const nbl_plan* plan, uint32_t launch,
-                               const char** kernel_name, uint32_t* n_tiles);
+/* One kernel launch of the plan (for profiling and roofline accounting). */
+typedef struct nbl_launch_info {
+  const char* kernel;      /* kernel family name, e.g. "k_materialize" */
+  uint32_t elem_bytes;     /* element-size specialisation (0 when not specialised) */
+  uint32_t n_tiles;        /* workgroups */
+  uint32_t level;          /* cascade step the launch belongs to */
+  uint32_t reserved;
+  /* Algorithmic bytes of the chunks whose final output this launch writes:
+   * their encoded bytes plus their decoded bytes (B_enc + B_out).  Launches
+   * that only produce intermediates carry 0, so the sum over all launches is
+   * info.encoded_bytes + info.decoded_bytes. */
+  uint64_t alg_bytes;
+} nbl_launch_info;
+
+nbl_status nbl_plan_get_launch(const nbl_plan* plan, uint32_t launch, nbl_launch_info* info);
+
+/*
+ * Per-launch timing with HIP events recorded on the decode stream (no
+ * counterpart in the reference; measurement only).  nbl_profile_create
+ * allocates 2 * n_launches * max_steps events; nbl_decode_batch_profiled is
+ * nbl_decode_batch_device plus an event before and after every launch of step
+ * `step` (< max_steps); nbl_profile_collect synchronises the last event and
+ * writes, for every launch, the mean duration in milliseconds over the steps
+ * recorded so far.
+ */
+typedef struct nbl_profile nbl_profile;
+nbl_status nbl_profile_create(const nbl_plan* plan, uint32_t max_steps, nbl_profile** profile_out);
+void nbl_profile_free(nbl_profile* profile);
+nbl_status nbl_decode_batch_profiled(const nbl_plan* plan, nbl_profile* profile, uint32_t step,
+                                     const void* d_arena, void* d_out, void* d_work, void* stream);
+nbl_status nbl_profile_collect(nbl_profile* profile, float* mean_ms_per_launch, uint32_t n_launches);
 
 /* Message of the calling thread's most recent failure (never NULL). */
 const char* nbl_last_error(void);

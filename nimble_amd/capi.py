@@ -24,6 +24,7 @@ EXPORTED_SYMBOLS = (
     "nbl_plan_batch", "nbl_plan_free", "nbl_plan_get_info", "nbl_plan_get_chunk_layout",
     "nbl_split_stream", "nbl_plan_upload", "nbl_decode_batch_device", "nbl_decode_status",
     "nbl_plan_get_launch", "nbl_last_error", "nbl_build_arch",
+    "nbl_profile_create", "nbl_profile_free", "nbl_decode_batch_profiled", "nbl_profile_collect",
 )
 
 
@@ -49,6 +50,11 @@ class NblChunkLayout(C.Structure):
     ]
 
 
+class NblLaunchInfo(C.Structure):
+    _fields_ = [("kernel", C.c_char_p), ("elem_bytes", C.c_uint32), ("n_tiles", C.c_uint32),
+                ("level", C.c_uint32), ("reserved", C.c_uint32), ("alg_bytes", C.c_uint64)]
+
+
 class NimbleError(RuntimeError):
     """Raised for every non-zero nbl_status; `.status` holds the code."""
 
@@ -72,7 +78,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        path = _build.LIB_PATH
+        path = os.environ.get("NIMBLE_AMD_LIB", _build.LIB_PATH)  # override: A/B builds while tuning
         if not os.path.exists(path):
             raise ImportError(
                 f"{path} is missing: run `python -m nimble_amd.build` (the decoder has no CPU fallback)")
@@ -97,7 +103,15 @@ def lib():
         L.nbl_decode_status.restype = C.c_int
         L.nbl_decode_status.argtypes = [vp, vp, vp]
         L.nbl_plan_get_launch.restype = C.c_int
-        L.nbl_plan_get_launch.argtypes = [vp, u32, C.POINTER(C.c_char_p), C.POINTER(u32)]
+        L.nbl_plan_get_launch.argtypes = [vp, u32, C.POINTER(NblLaunchInfo)]
+        L.nbl_profile_create.restype = C.c_int
+        L.nbl_profile_create.argtypes = [vp, u32, C.POINTER(vp)]
+        L.nbl_profile_free.restype = None
+        L.nbl_profile_free.argtypes = [vp]
+        L.nbl_decode_batch_profiled.restype = C.c_int
+        L.nbl_decode_batch_profiled.argtypes = [vp, vp, u32, vp, vp, vp, vp]
+        L.nbl_profile_collect.restype = C.c_int
+        L.nbl_profile_collect.argtypes = [vp, C.POINTER(C.c_float), u32]
         _lib = L
     return _lib
 

@@ -54,6 +54,8 @@ enum KernelId : uint32_t {
   K_STRING_VIEWS,      // lengths -> {offset,len}
   K_COPY_BYTES,        // string blobs arena -> out
   K_SELECT_BITS,       // Nullable<bool>: scatter a bitmap by a bitmap
+  K_MATERIALIZE_FBW,   // root FixedBitWidth, window-per-vector fast path
+  K_MATERIALIZE_RAW,   // root Trivial / byte-aligned FixedBitWidth: copy (+ baseline)
   K_COUNT
 };
 
@@ -81,7 +83,8 @@ struct NodeDesc {
   uint64_t aux;       // fill value (Nullable: 0, MainlyConstant: common value);
                       // K_COPY_BYTES: byte count; K_STRING_VIEWS: blob base offset
   uint64_t aux_off;   // second array: run ends (work) / nulls bitmap (out) / copy src (arena)
-  uint64_t aux2;      // K_STRING_VIEWS: blob bytes; varint: payload byte count
+  uint64_t aux2;      // K_STRING_VIEWS: blob bytes; varint: payload byte count;
+                      // select kernels: rows per tile of the popcount partials
   uint32_t rows;      // rows of this node
   uint32_t flags;     // NodeFlags
   uint32_t part_base; // first slot of this node in the tile-partials array

@@ -201,7 +201,9 @@ template <int ES>
 __device__ __forceinline__ void store_vec(typename ElemT<ES>::type* dst, uint64_t e0, uint64_t rows, const Vec16<ES>& x) {
   constexpr uint32_t V = 16 / ES;
   if (e0 + V <= rows) {
-    *reinterpret_cast<u32x4*>(dst + e0) = x.q;
+    // decoded columns are written once and not re-read by this pass: a
+    // non-temporal store keeps them out of the caches' write-allocate path
+    __builtin_nontemporal_store(x.q, reinterpret_cast<u32x4*>(dst + e0));
   } else {
 #pragma unroll
     for (uint32_t j = 0; j < V; ++j)
@@ -218,6 +220,118 @@ __device__ __forceinline__ uint8_t* self_ptr(const NodeDesc& nd, const KArgs& a)
 // straight into the output.  FixedBitWidthEncoding::materialize
 // (encodings/FixedBitWidthEncoding.h:187-192), TrivialEncoding::materialize
 // (encodings/TrivialEncoding.h:295-300), ConstantEncoding (ConstantEncoding.h:72-77).
+//
+// Three launch variants keep each inner loop branch free:
+//   k_materialize_fbw : bit widths whose 16-byte output vector (V = 16/ES values)
+//                       is covered by one 16-byte window of packed bits
+//   k_materialize_raw : byte-aligned elements (Trivial, or bit width == 8*ES),
+//                       copy + baseline
+//   k_materialize     : everything else (Constant fill, odd width/type pairs)
+
+// Widths the window kernel handles (the planner uses the same predicate).
+__host__ __device__ constexpr bool fbw_window_ok(uint32_t es, uint32_t w) {
+  // V*w + (first-bit offset within its byte) must fit 128 bits; the offset is
+  // (e0*w)&7 with e0 a multiple of V, so it is 0 for ES<=2, {0,4} for ES=4 and
+  // {0,2,4,6} for ES=8.
+  // Width 63 (ES=8) overruns the window by up to 4 bits: the kernel then reads a fifth dword.
+  return w >= 1 && (es == 8 ? w <= 63 : es == 4 ? w <= 31 : es == 2 ? w <= 15 : w <= 7);
+}
+
+template <int ES>
+__global__ __launch_bounds__(256) void k_materialize_fbw(KArgs a) {
+  using T = typename ElemT<ES>::type;
+  constexpr uint32_t V = 16 / ES;
+  constexpr uint32_t TE = kTileBytes / ES;
+  const TileRef tr = a.tiles[blockIdx.x];
+  const NodeDesc& nd = a.nodes[tr.node];
+  const uint64_t rows = nd.rows;
+  const uint64_t start = (uint64_t)tr.tile * TE;
+  const uint32_t w = nd.c0.width;           // wave uniform
+  const T base = (T)nd.c0.base;
+  T* dst = reinterpret_cast<T*>(self_ptr(nd, a)) + start;
+  const uint64_t tile_bit = start * w;      // scalar 64-bit
+  const uint8_t* tile_src = a.arena + nd.c0.off + (tile_bit >> 3);
+  const uint32_t tile_sh = (uint32_t)tile_bit & 7u;
+  const uint32_t tile_rows = rows - start < TE ? (uint32_t)(rows - start) : TE;
+  const uint32_t mask32 = w >= 32 ? 0xFFFFFFFFu : ((1u << w) - 1u);
+#pragma unroll
+  for (uint32_t it = 0; it < 4; ++it) {
+    const uint32_t q = (it * kBlock + threadIdx.x) * V;  // first row of this lane's vector, tile relative
+    if (q >= tile_rows) break;
+    const uint32_t lb = tile_sh + q * w;                 // < 16384*62 + 8: 20 bits
+    u32x4 d;
+    __builtin_memcpy(&d, tile_src + (lb >> 3), 16);      // packed bytes + 7 bytes slop keep this in bounds
+    const uint32_t S = lb & 7u;
+    // normalise: n = window >> S
+    uint32_t n0 = __builtin_amdgcn_alignbit(d.y, d.x, S);
+    uint32_t n1 = __builtin_amdgcn_alignbit(d.z, d.y, S);
+    uint32_t n2 = __builtin_amdgcn_alignbit(d.w, d.z, S);
+    uint32_t n3 = d.w >> S;
+    if constexpr (ES == 8) {
+      if (w == 63) n3 = __builtin_amdgcn_alignbit(ldu32(tile_src + (lb >> 3) + 16), d.w, S);  // bits 128..131
+    }
+    Vec16<ES> x;
+    if constexpr (ES == 8) {
+      if (w < 32) {
+        const uint32_t v0 = n0 & mask32;
+        n0 = __builtin_amdgcn_alignbit(n1, n0, w);
+        x.v[0] = (uint64_t)v0 + base;
+        x.v[1] = (uint64_t)(n0 & mask32) + base;
+      } else {
+        const uint32_t wh = w - 32;                       // 0..30
+        const uint32_t maskh = (1u << wh) - 1u;           // wh == 0 -> 0
+        x.v[0] = (((uint64_t)(n1 & maskh) << 32) | n0) + base;
+        // drop w bits: one dword, then wh more
+        const uint32_t m0 = __builtin_amdgcn_alignbit(n2, n1, wh);
+        const uint32_t m1 = __builtin_amdgcn_alignbit(n3, n2, wh);
+        x.v[1] = (((uint64_t)(m1 & maskh) << 32) | m0) + base;
+      }
+    } else {
+#pragma unroll
+      for (uint32_t j = 0; j < V; ++j) {
+        x.v[j] = (T)((T)(n0 & mask32) + base);
+        n0 = __builtin_amdgcn_alignbit(n1, n0, w);
+        n1 = __builtin_amdgcn_alignbit(n2, n1, w);
+        n2 = __builtin_amdgcn_alignbit(n3, n2, w);
+        n3 >>= w;
+      }
+    }
+    store_vec<ES>(dst, q, tile_rows, x);
+  }
+}
+
+template <int ES>
+__global__ __launch_bounds__(256) void k_materialize_raw(KArgs a) {
+  using T = typename ElemT<ES>::type;
+  constexpr uint32_t V = 16 / ES;
+  constexpr uint32_t TE = kTileBytes / ES;
+  const TileRef tr = a.tiles[blockIdx.x];
+  const NodeDesc& nd = a.nodes[tr.node];
+  const uint64_t rows = nd.rows;
+  const uint64_t start = (uint64_t)tr.tile * TE;
+  const T base = nd.c0.kind == COL_FBW ? (T)nd.c0.base : (T)0;
+  const uint8_t* src = a.arena + nd.c0.off + start * ES;
+  T* dst = reinterpret_cast<T*>(self_ptr(nd, a)) + start;
+  const uint32_t tile_rows = rows - start < TE ? (uint32_t)(rows - start) : TE;
+#pragma unroll
+  for (uint32_t it = 0; it < 4; ++it) {
+    const uint32_t q = (it * kBlock + threadIdx.x) * V;
+    if (q >= tile_rows) break;
+    Vec16<ES> x;
+    if (q + V <= tile_rows) {
+      __builtin_memcpy(&x.q, src + (size_t)q * ES, 16);
+    } else {
+      x.q = make_u32x4(0, 0, 0, 0);
+#pragma unroll
+      for (uint32_t j = 0; j < V; ++j)
+        if (q + j < tile_rows) __builtin_memcpy(&x.v[j], src + (size_t)(q + j) * ES, ES);
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < V; ++j) x.v[j] = (T)(x.v[j] + base);
+    store_vec<ES>(dst, q, tile_rows, x);
+  }
+}
+
 template <int ES>
 __global__ __launch_bounds__(256) void k_materialize(KArgs a) {
   using T = typename ElemT<ES>::type;
@@ -229,44 +343,14 @@ __global__ __launch_bounds__(256) void k_materialize(KArgs a) {
   const uint64_t rows = nd.rows;
   const uint64_t start = (uint64_t)tr.tile * TE;
   T* dst = reinterpret_cast<T*>(self_ptr(nd, a));
-  if (src.kind == COL_FBW) {
-    const uint8_t* payload = a.arena + src.off;
-    const uint32_t w = src.width;
-    const T base = (T)src.base;
 #pragma unroll
-    for (uint32_t it = 0; it < 4; ++it) {
-      const uint64_t e0 = start + (uint64_t)(it * kBlock + threadIdx.x) * V;
-      if (e0 >= rows) break;
-      Vec16<ES> x;
+  for (uint32_t it = 0; it < 4; ++it) {
+    const uint64_t e0 = start + (uint64_t)(it * kBlock + threadIdx.x) * V;
+    if (e0 >= rows) break;
+    Vec16<ES> x;
 #pragma unroll
-      for (uint32_t j = 0; j < V; ++j) x.v[j] = (T)((T)fbw_get(payload, w, e0 + j < rows ? e0 + j : rows - 1) + base);
-      store_vec<ES>(dst, e0, rows, x);
-    }
-  } else if (src.kind == COL_RAW) {
-    const uint8_t* p = a.arena + src.off;
-#pragma unroll
-    for (uint32_t it = 0; it < 4; ++it) {
-      const uint64_t e0 = start + (uint64_t)(it * kBlock + threadIdx.x) * V;
-      if (e0 >= rows) break;
-      Vec16<ES> x;
-      if (e0 + V <= rows) {
-        __builtin_memcpy(&x.q, p + e0 * ES, 16);
-      } else {
-#pragma unroll
-        for (uint32_t j = 0; j < V; ++j) x.v[j] = e0 + j < rows ? (T)col_get(src, a, e0 + j) : (T)0;
-      }
-      store_vec<ES>(dst, e0, rows, x);
-    }
-  } else {  // COL_CONST or an already materialised column
-#pragma unroll
-    for (uint32_t it = 0; it < 4; ++it) {
-      const uint64_t e0 = start + (uint64_t)(it * kBlock + threadIdx.x) * V;
-      if (e0 >= rows) break;
-      Vec16<ES> x;
-#pragma unroll
-      for (uint32_t j = 0; j < V; ++j) x.v[j] = (T)col_get(src, a, e0 + j < rows ? e0 + j : rows - 1);
-      store_vec<ES>(dst, e0, rows, x);
-    }
+    for (uint32_t j = 0; j < V; ++j) x.v[j] = (T)col_get(src, a, e0 + j < rows ? e0 + j : rows - 1);
+    store_vec<ES>(dst, e0, rows, x);
   }
 }
 
@@ -866,6 +950,8 @@ extern "C" int nbl_launch_kernel(uint32_t kernel, uint32_t es, const nbl::KArgs*
   }
   switch (kernel) {
     case K_MATERIALIZE: NBL_BY_ES(k_materialize); break;
+    case K_MATERIALIZE_FBW: NBL_BY_ES(k_materialize_fbw); break;
+    case K_MATERIALIZE_RAW: NBL_BY_ES(k_materialize_raw); break;
     case K_BITS_TO_BYTES: hipLaunchKernelGGL(k_bits_to_bytes, grid, block, 0, s, a); break;
     case K_REDUCE_SUM: hipLaunchKernelGGL(k_reduce_sum, grid, block, 0, s, a); break;
     case K_REDUCE_POPC: hipLaunchKernelGGL(k_reduce_popc, grid, block, 0, s, a); break;

@@ -95,18 +95,21 @@ struct Step {
   uint32_t dnode;
   uint32_t n_tiles;
   bool per_node;  // K_SCAN_TILES: one workgroup, tile index unused
+  int chunk;      // >= 0 when this step writes the final values of that chunk
 };
 
 struct Launch {
   uint32_t kernel, es;
   uint32_t tile_begin, n_tiles;
+  int level;
+  uint64_t alg_bytes;
 };
 
 const char* kKernelNames[K_COUNT] = {
     "k_materialize", "k_bits_to_bytes", "k_reduce_sum", "k_reduce_popc", "k_reduce_varint",
     "k_scan_tiles", "k_rle_ends", "k_rle_expand", "k_rle_expand_bool", "k_sparse_bits",
     "k_select_scatter", "k_dict_gather", "k_varint_decode", "k_string_views", "k_copy_bytes",
-    "k_select_bits"};
+    "k_select_bits", "k_materialize_fbw", "k_materialize_raw"};
 
 }  // namespace
 
@@ -120,6 +123,8 @@ struct nbl_plan {
   std::vector<NodeDesc> dnodes;
   std::vector<uint8_t> aux_in_work;       // per dnode: aux_off is an offset into work (run ends)
   std::vector<uint32_t> chunk_copies;     // dnodes of the string copies of the chunk being planned
+  std::vector<int> chunk_final_step;      // per chunk: index into steps (before sorting) or -1
+  std::vector<uint64_t> chunk_sizes;
   std::vector<Step> steps;
   std::vector<Launch> launches;
   std::vector<TileRef> tiles;
@@ -152,7 +157,7 @@ struct nbl_plan {
   }
   void add_step(int level, uint32_t kernel, uint32_t es, uint32_t dnode, uint32_t n_tiles, bool per_node = false) {
     if (n_tiles == 0) return;
-    steps.push_back(Step{level, kernel, es, dnode, n_tiles, per_node});
+    steps.push_back(Step{level, kernel, es, dnode, n_tiles, per_node, -1});
   }
   void alloc_scan(NodeDesc& d, uint32_t n_tiles) {
     d.part_base = n_parts; d.n_parts = n_tiles; n_parts += n_tiles;
@@ -583,7 +588,12 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       d.self = *root_dst; d.self.rows = rows; d.self.es = (uint8_t)es;
       d.c0 = r.ref; d.rows = rows;
       const uint32_t dn = add_dnode(d);
-      add_step(r.ready, K_MATERIALIZE, es, dn, div_up32(rows, tile_rows));
+      uint32_t kernel = K_MATERIALIZE;
+      const uint32_t w = r.ref.width;
+      const bool window = w >= 1 && (es == 8 ? w <= 63 : es == 4 ? w <= 31 : es == 2 ? w <= 15 : w <= 7);
+      if (r.ref.kind == COL_RAW || (r.ref.kind == COL_FBW && w == 8 * es)) kernel = K_MATERIALIZE_RAW;
+      else if (r.ref.kind == COL_FBW && window) kernel = K_MATERIALIZE_FBW;
+      add_step(r.ready, kernel, es, dn, div_up32(rows, tile_rows));
       r.ready += 1;
     }
   }
@@ -609,12 +619,21 @@ void nbl_plan::plan_chunk(uint32_t c, uint64_t off, uint64_t size) {
   ColRef dst{};
   dst.kind = COL_MAT_OUT; dst.off = L.values_offset; dst.rows = r.rows; dst.es = L.elem_bytes;
   cur_str = 0;
+  const size_t first_step = steps.size();
   place(root, true, &dst);
+  {  // the step that writes the chunk's values: the latest one of this chunk
+    int best = -1;
+    for (size_t i = first_step; i < steps.size(); ++i)
+      if (steps[i].kernel != K_COPY_BYTES && (best < 0 || steps[i].level >= steps[(size_t)best].level)) best = (int)i;
+    if (best >= 0) steps[(size_t)best].chunk = (int)c;
+    chunk_final_step.push_back(best);
+  }
   if (r.is_string) {
     L.string_bytes = cur_str;
     L.string_offset = alloc_out(cur_str);
     for (uint32_t dn : chunk_copies) dnodes[dn].self.off += L.string_offset;
   }
+  chunk_sizes.push_back(size);
   encoded_bytes += size;
   decoded_bytes += L.values_bytes + L.nulls_bytes;
   total_rows += r.rows;
@@ -628,9 +647,13 @@ void nbl_plan::finish() {
   });
   for (size_t i = 0; i < steps.size();) {
     size_t j = i;
-    Launch L{steps[i].kernel, steps[i].es, (uint32_t)tiles.size(), 0};
+    Launch L{steps[i].kernel, steps[i].es, (uint32_t)tiles.size(), 0, steps[i].level, 0};
     while (j < steps.size() && steps[j].level == steps[i].level && steps[j].kernel == steps[i].kernel && steps[j].es == steps[i].es) {
       for (uint32_t t = 0; t < steps[j].n_tiles; ++t) tiles.push_back(TileRef{steps[j].dnode, t});
+      if (steps[j].chunk >= 0) {
+        const nbl_chunk_layout& cl = layouts[(size_t)steps[j].chunk];
+        L.alg_bytes += chunk_sizes[(size_t)steps[j].chunk] + cl.values_bytes + cl.nulls_bytes + cl.string_bytes;
+      }
       ++j;
     }
     L.n_tiles = (uint32_t)tiles.size() - L.tile_begin;
@@ -737,10 +760,15 @@ nbl_status nbl_plan_get_chunk_layout(const nbl_plan* p, uint32_t chunk, nbl_chun
   return NBL_OK;
 }
 
-nbl_status nbl_plan_get_launch(const nbl_plan* p, uint32_t launch, const char** kernel_name, uint32_t* n_tiles) {
-  if (!p || launch >= p->launches.size()) { g_last_error = "bad launch index"; return NBL_ERR_ARGUMENT; }
-  if (kernel_name) *kernel_name = kKernelNames[p->launches[launch].kernel];
-  if (n_tiles) *n_tiles = p->launches[launch].n_tiles;
+nbl_status nbl_plan_get_launch(const nbl_plan* p, uint32_t launch, nbl_launch_info* info) {
+  if (!p || !info || launch >= p->launches.size()) { g_last_error = "bad launch index"; return NBL_ERR_ARGUMENT; }
+  const Launch& L = p->launches[launch];
+  info->kernel = kKernelNames[L.kernel];
+  info->elem_bytes = L.es;
+  info->n_tiles = L.n_tiles;
+  info->level = (uint32_t)L.level;
+  info->reserved = 0;
+  info->alg_bytes = L.alg_bytes;
   return NBL_OK;
 }
 
@@ -757,7 +785,70 @@ nbl_status nbl_plan_upload(nbl_plan* p, void* d_work, void* stream) {
   return NBL_OK;
 }
 
+}  // extern "C"
+
+struct nbl_profile {
+  uint32_t n_launches = 0, max_steps = 0, steps_recorded = 0;
+  std::vector<hipEvent_t> events;  // [step][launch][begin,end]
+};
+
+static nbl_status decode_impl(const nbl_plan* p, nbl_profile* prof, uint32_t step, const void* d_arena, void* d_out,
+                              void* d_work, void* stream);
+
+extern "C" {
+
 nbl_status nbl_decode_batch_device(const nbl_plan* p, const void* d_arena, void* d_out, void* d_work, void* stream) {
+  return decode_impl(p, nullptr, 0, d_arena, d_out, d_work, stream);
+}
+
+nbl_status nbl_profile_create(const nbl_plan* p, uint32_t max_steps, nbl_profile** out) {
+  if (!p || !out || max_steps == 0) { g_last_error = "bad argument"; return NBL_ERR_ARGUMENT; }
+  nbl_profile* pr = new nbl_profile();
+  pr->n_launches = (uint32_t)p->launches.size();
+  pr->max_steps = max_steps;
+  pr->events.resize((size_t)2 * pr->n_launches * max_steps, nullptr);
+  for (hipEvent_t& e : pr->events) {
+    hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) { nbl_profile_free(pr); g_last_error = std::string("hipEventCreate: ") + hipGetErrorString(rc); return NBL_ERR_HIP; }
+  }
+  *out = pr;
+  return NBL_OK;
+}
+
+void nbl_profile_free(nbl_profile* pr) {
+  if (!pr) return;
+  for (hipEvent_t e : pr->events) if (e) (void)hipEventDestroy(e);
+  delete pr;
+}
+
+nbl_status nbl_decode_batch_profiled(const nbl_plan* p, nbl_profile* pr, uint32_t step, const void* d_arena, void* d_out,
+                                     void* d_work, void* stream) {
+  if (!pr || step >= pr->max_steps || !p || pr->n_launches != p->launches.size()) { g_last_error = "bad profile argument"; return NBL_ERR_ARGUMENT; }
+  const nbl_status st = decode_impl(p, pr, step, d_arena, d_out, d_work, stream);
+  if (st == NBL_OK && step + 1 > pr->steps_recorded) pr->steps_recorded = step + 1;
+  return st;
+}
+
+nbl_status nbl_profile_collect(nbl_profile* pr, float* mean_ms, uint32_t n_launches) {
+  if (!pr || !mean_ms || n_launches != pr->n_launches) { g_last_error = "bad profile argument"; return NBL_ERR_ARGUMENT; }
+  for (uint32_t l = 0; l < n_launches; ++l) mean_ms[l] = 0.f;
+  if (pr->steps_recorded == 0 || n_launches == 0) return NBL_OK;
+  hipError_t rc = hipEventSynchronize(pr->events[((size_t)(pr->steps_recorded - 1) * n_launches + (n_launches - 1)) * 2 + 1]);
+  if (rc != hipSuccess) { g_last_error = std::string("hipEventSynchronize: ") + hipGetErrorString(rc); return NBL_ERR_HIP; }
+  for (uint32_t s = 0; s < pr->steps_recorded; ++s)
+    for (uint32_t l = 0; l < n_launches; ++l) {
+      float ms = 0.f;
+      rc = hipEventElapsedTime(&ms, pr->events[((size_t)s * n_launches + l) * 2], pr->events[((size_t)s * n_launches + l) * 2 + 1]);
+      if (rc != hipSuccess) { g_last_error = std::string("hipEventElapsedTime: ") + hipGetErrorString(rc); return NBL_ERR_HIP; }
+      mean_ms[l] += ms / (float)pr->steps_recorded;
+    }
+  return NBL_OK;
+}
+
+}  // extern "C"
+
+static nbl_status decode_impl(const nbl_plan* p, nbl_profile* prof, uint32_t step, const void* d_arena, void* d_out,
+                              void* d_work, void* stream) {
   if (!p || !d_work || (!d_arena && p->span) || !d_out) { g_last_error = "null argument"; return NBL_ERR_ARGUMENT; }
   uint8_t* work = static_cast<uint8_t*>(d_work);
   hipError_t e = hipMemsetAsync(work + p->ctrl_off, 0, p->ctrl_bytes, static_cast<hipStream_t>(stream));
@@ -771,10 +862,14 @@ nbl_status nbl_decode_batch_device(const nbl_plan* p, const void* d_arena, void*
   a.totals = a.status + 1;
   a.parts = reinterpret_cast<uint32_t*>(work + p->parts_off);
   const TileRef* tiles = reinterpret_cast<const TileRef*>(work + p->tiles_off);
-  for (const Launch& L : p->launches) {
+  const size_t nl = p->launches.size();
+  for (size_t li = 0; li < nl; ++li) {
+    const Launch& L = p->launches[li];
     a.tiles = tiles + L.tile_begin;
     a.n_tiles = L.n_tiles;
+    if (prof) (void)hipEventRecord(prof->events[((size_t)step * nl + li) * 2], static_cast<hipStream_t>(stream));
     const int rc = nbl_launch_kernel(L.kernel, L.es, &a, stream);
+    if (prof) (void)hipEventRecord(prof->events[((size_t)step * nl + li) * 2 + 1], static_cast<hipStream_t>(stream));
     if (rc != 0) {
       g_last_error = std::string("launch of ") + kKernelNames[L.kernel] + " failed";
       return NBL_ERR_HIP;
@@ -782,6 +877,8 @@ nbl_status nbl_decode_batch_device(const nbl_plan* p, const void* d_arena, void*
   }
   return NBL_OK;
 }
+
+extern "C" {
 
 nbl_status nbl_decode_status(const nbl_plan* p, const void* d_work, void* stream) {
   if (!p || !d_work) { g_last_error = "null argument"; return NBL_ERR_ARGUMENT; }

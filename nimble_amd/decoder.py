@@ -66,12 +66,12 @@ class Plan:
         return Plan(buf, offs, varint_rows)
 
     def launches(self):
+        """[(kernel, elem_bytes, n_tiles, level, alg_bytes)] in launch order."""
         out = []
         for i in range(self.info.n_launches):
-            name = C.c_char_p()
-            nt = C.c_uint32()
-            capi.check(capi.lib().nbl_plan_get_launch(self._h, i, C.byref(name), C.byref(nt)))
-            out.append((name.value.decode(), nt.value))
+            li = capi.NblLaunchInfo()
+            capi.check(capi.lib().nbl_plan_get_launch(self._h, i, C.byref(li)))
+            out.append((li.kernel.decode(), int(li.elem_bytes), int(li.n_tiles), int(li.level), int(li.alg_bytes)))
         return out
 
     def close(self):
@@ -123,6 +123,26 @@ class BatchDecoder:
             capi.check(capi.lib().nbl_decode_batch_device(
                 self.plan._h, C.c_void_p(self.arena.data_ptr()), C.c_void_p(self.out.data_ptr()),
                 C.c_void_p(self.work.data_ptr()), self._stream_ptr()))
+
+    def profile_begin(self, max_steps: int):
+        self._prof = C.c_void_p()
+        capi.check(capi.lib().nbl_profile_create(self.plan._h, max_steps, C.byref(self._prof)))
+
+    def decode_profiled(self, step: int):
+        """decode() with a HIP event before and after every launch."""
+        with self.torch.cuda.device(self.device):
+            capi.check(capi.lib().nbl_decode_batch_profiled(
+                self.plan._h, self._prof, step, C.c_void_p(self.arena.data_ptr()), C.c_void_p(self.out.data_ptr()),
+                C.c_void_p(self.work.data_ptr()), self._stream_ptr()))
+
+    def profile_end(self):
+        """Mean milliseconds per launch over the profiled steps."""
+        n = int(self.plan.info.n_launches)
+        ms = (C.c_float * max(n, 1))()
+        capi.check(capi.lib().nbl_profile_collect(self._prof, ms, n))
+        capi.lib().nbl_profile_free(self._prof)
+        self._prof = None
+        return [float(ms[i]) for i in range(n)]
 
     def status(self):
         with self.torch.cuda.device(self.device):
