@@ -124,7 +124,7 @@ struct nbl_plan {
   std::vector<uint8_t> aux_in_work;       // per dnode: aux_off is an offset into work (run ends)
   std::vector<uint32_t> chunk_copies;     // dnodes of the string copies of the chunk being planned
   std::vector<int> chunk_final_step;      // per chunk: index into steps (before sorting) or -1
-  std::vector<uint64_t> chunk_sizes;
+  std::vector<uint64_t> chunk_alg;        // per chunk: encoded + decoded bytes
   std::vector<Step> steps;
   std::vector<Launch> launches;
   std::vector<TileRef> tiles;
@@ -619,6 +619,7 @@ void nbl_plan::plan_chunk(uint32_t c, uint64_t off, uint64_t size) {
   ColRef dst{};
   dst.kind = COL_MAT_OUT; dst.off = L.values_offset; dst.rows = r.rows; dst.es = L.elem_bytes;
   cur_str = 0;
+  const uint64_t decoded_before = decoded_bytes;  // string_copy adds the string bytes while placing
   const size_t first_step = steps.size();
   place(root, true, &dst);
   {  // the step that writes the chunk's values: the latest one of this chunk
@@ -633,9 +634,9 @@ void nbl_plan::plan_chunk(uint32_t c, uint64_t off, uint64_t size) {
     L.string_offset = alloc_out(cur_str);
     for (uint32_t dn : chunk_copies) dnodes[dn].self.off += L.string_offset;
   }
-  chunk_sizes.push_back(size);
   encoded_bytes += size;
   decoded_bytes += L.values_bytes + L.nulls_bytes;
+  chunk_alg.push_back(size + (decoded_bytes - decoded_before));
   total_rows += r.rows;
 }
 
@@ -651,8 +652,7 @@ void nbl_plan::finish() {
     while (j < steps.size() && steps[j].level == steps[i].level && steps[j].kernel == steps[i].kernel && steps[j].es == steps[i].es) {
       for (uint32_t t = 0; t < steps[j].n_tiles; ++t) tiles.push_back(TileRef{steps[j].dnode, t});
       if (steps[j].chunk >= 0) {
-        const nbl_chunk_layout& cl = layouts[(size_t)steps[j].chunk];
-        L.alg_bytes += chunk_sizes[(size_t)steps[j].chunk] + cl.values_bytes + cl.nulls_bytes + cl.string_bytes;
+        L.alg_bytes += chunk_alg[(size_t)steps[j].chunk];
       }
       ++j;
     }

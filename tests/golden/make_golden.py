@@ -1,0 +1,271 @@
+#!/usr/bin/env python3
+"""Writes tests/golden/golden_v1.json: hand-assembled encoded byte vectors with
+their expected decoded output.
+
+Independence: this script uses neither nimble_amd.encoder nor the oracle.  Every
+vector is assembled with struct.pack from the byte layouts the reference
+documents and hand-assembles in its own tests, and the expected output is the
+input the reference's tests feed (so the answer is known by construction):
+
+  prefix ............ encodings/common/EncodingPrefix.h:26-54
+  FixedBitWidth ..... encodings/tests/FixedBitWidthEncodingTest.cpp:76-103 (hand assembly),
+                      :122-138, :140-188 ({0..9}, {0..52}, bit-width byte 8 / 6)
+  FixedBitArray ..... common/tests/FixedBitArrayTests.cpp:27-39 ((i+i*i)%1024 at 10 bits),
+                      :151-170 (100-i at 7 bits); packing rule common/FixedBitArray.cpp:68-82
+  RLE ............... encodings/RLEEncoding.h:102-106,428-431,741-745,
+                      encodings/tests/RLEEncodingTest.cpp:142-148,184-195
+  Nullable .......... encodings/tests/EncodingTest.cpp:1092-1105 (hand assembly)
+  MainlyConstant .... encodings/tests/EncodingTest.cpp:1185-1202,1264-1282 (hand assembly)
+  Dictionary ........ encodings/DictionaryEncoding.h:41-45
+  SparseBool ........ encodings/SparseBoolEncoding.h:44-47, SparseBoolEncoding.cpp:215-217
+  Constant .......... encodings/ConstantEncoding.h:33-35
+  Trivial ........... encodings/TrivialEncoding.h:40-44,105-110,191-194
+  Varint ............ encodings/VarintEncoding.h:37-40, common/Varint.h:70-76
+  chunk header ...... common/ChunkHeader.h:25-47
+
+Run:  python tests/golden/make_golden.py
+"""
+import json
+import os
+import struct
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+TRIVIAL, RLE, DICT, FBW, NULLABLE, SPARSE, VARINT, CONST, MC = 0, 1, 2, 3, 5, 6, 7, 9, 10
+I8, U8, I16, U16, I32, U32, I64, U64, F32, F64, BOOL, STR = range(1, 13)
+ES = {I8: 1, U8: 1, I16: 2, U16: 2, I32: 4, U32: 4, I64: 8, U64: 8, F32: 4, F64: 8}
+FMT = {1: "B", 2: "H", 4: "I", 8: "Q"}
+
+
+def varint(v):
+    out = bytearray()
+    while v >= 128:
+        out.append(0x80 | (v & 0x7F))
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def prefix(enc, dt, rows, vr=False):
+    return bytes([enc, dt]) + (varint(rows) if vr else struct.pack("<I", rows))
+
+
+def raw(vals, dt):
+    return b"".join(struct.pack("<" + FMT[ES[dt]], v & ((1 << (8 * ES[dt])) - 1)) for v in vals)
+
+
+def pack_bits(vals, w):
+    """FixedBitArray::set: value i OR-ed into bits [i*w, (i+1)*w), LSB first; +7 bytes of slop."""
+    acc = 0
+    for i, v in enumerate(vals):
+        assert 0 <= v < (1 << w)
+        acc |= v << (i * w)
+    nbytes = (len(vals) * w + 7) // 8
+    return acc.to_bytes(nbytes, "little") + bytes(7)
+
+
+def fbw(vals, dt, w, base=0, vr=False):
+    return (prefix(FBW, dt, len(vals), vr) + b"\x00" + raw([base], dt) + bytes([w]) +
+            pack_bits([(v - base) & ((1 << (8 * ES[dt])) - 1) for v in vals], w))
+
+
+def trivial(vals, dt, vr=False):
+    if dt == BOOL:
+        return prefix(TRIVIAL, BOOL, len(vals), vr) + b"\x00" + pack_bits([int(b) for b in vals], 1)
+    if dt == STR:
+        lens = trivial([len(s) for s in vals], U32, vr)
+        return prefix(TRIVIAL, STR, len(vals), vr) + b"\x00" + struct.pack("<I", len(lens)) + lens + b"".join(vals)
+    return prefix(TRIVIAL, dt, len(vals), vr) + b"\x00" + raw(vals, dt)
+
+
+def runs_of(vals):
+    lens, rv = [], []
+    for v in vals:
+        if rv and rv[-1] == v:
+            lens[-1] += 1
+        else:
+            rv.append(v)
+            lens.append(1)
+    return lens, rv
+
+
+def rle(vals, dt, child=trivial, vr=False):
+    lens, rv = runs_of(vals)
+    le = child(lens, U32, vr)
+    head = prefix(RLE, dt, len(vals), vr) + struct.pack("<I", len(le)) + le
+    if dt == BOOL:
+        return head + bytes([int(vals[0])])
+    return head + child(rv, dt, vr)
+
+
+def dictionary(vals, dt, vr=False):
+    alphabet = []
+    for v in vals:
+        if v not in alphabet:
+            alphabet.append(v)
+    idx = [alphabet.index(v) for v in vals]
+    a = trivial(alphabet, dt, vr)
+    return prefix(DICT, dt, len(vals), vr) + struct.pack("<I", len(a)) + a + trivial(idx, U32, vr)
+
+
+def sparse_bool(bools, vr=False):
+    n = len(bools)
+    ones = sum(bools)
+    sparse_value = not (ones > (n >> 1))
+    idx = [i for i, b in enumerate(bools) if bool(b) == sparse_value] + [n]
+    return prefix(SPARSE, BOOL, n, vr) + bytes([int(sparse_value)]) + trivial(idx, U32, vr)
+
+
+def constant(value, rows, dt, vr=False):
+    if dt == STR:
+        return prefix(CONST, STR, rows, vr) + struct.pack("<I", len(value)) + value
+    if dt == BOOL:
+        return prefix(CONST, BOOL, rows, vr) + bytes([int(value)])
+    return prefix(CONST, dt, rows, vr) + raw([value], dt)
+
+
+def nullable(data_enc, mask, dt, nulls_enc=None, vr=False):
+    ne = nulls_enc if nulls_enc is not None else trivial(mask, BOOL, vr)
+    return prefix(NULLABLE, dt, len(mask), vr) + struct.pack("<I", len(data_enc)) + data_enc + ne
+
+
+def mainly_constant(vals, dt, common, other_enc, is_common_enc=None, vr=False):
+    ic = [v == common for v in vals]
+    ice = is_common_enc if is_common_enc is not None else trivial(ic, BOOL, vr)
+    cv = (struct.pack("<I", len(common)) + common) if dt == STR else raw([common], dt)
+    return (prefix(MC, dt, len(vals), vr) + struct.pack("<I", len(ice)) + ice +
+            struct.pack("<I", len(other_enc)) + other_enc + cv)
+
+
+def varint_enc(vals, dt, base=None, vr=False):
+    base = min(vals) if base is None else base
+    return prefix(VARINT, dt, len(vals), vr) + raw([base], dt) + b"".join(varint(v - base) for v in vals)
+
+
+CASES = []
+
+
+def add(name, enc, dt, expected, nulls=None, vr=False, source=""):
+    c = {"name": name, "data_type": dt, "varint_rows": vr, "hex": enc.hex(), "source": source}
+    if dt == STR:
+        c["expected_strings_hex"] = [s.hex() for s in expected]
+    elif dt == BOOL:
+        c["expected"] = [int(b) for b in expected]
+    else:
+        m = (1 << (8 * ES[dt])) - 1
+        c["expected"] = [int(v) & m for v in expected]
+    if nulls is not None:
+        c["expected_non_null"] = [int(b) for b in nulls]
+    CASES.append(c)
+
+
+def main():
+    r53 = list(range(53))
+    add("fbw_u32_0to52_byte_rounded", fbw(r53, U32, 8), U32, r53,
+        source="FixedBitWidthEncodingTest.cpp:76-103,190-199 (encodeByteRounded)")
+    add("fbw_u32_0to52_exact_6bits", fbw(r53, U32, 6), U32, r53,
+        source="FixedBitWidthEncodingTest.cpp:140-188 (bit-width byte == 6 with exact bits)")
+    add("fbw_u32_0to52_varint_prefix", fbw(r53, U32, 8, vr=True), U32, r53, vr=True,
+        source="FixedBitWidthEncodingTest.cpp:118 (FBWTestConfig<true>)")
+    r10 = list(range(10))
+    add("fbw_u32_0to9", fbw(r10, U32, 8), U32, r10, source="FixedBitWidthEncodingTest.cpp:122-138")
+    add("fbw_u32_single_42", fbw([42], U32, 8, base=42), U32, [42], source="FixedBitWidthEncodingTest.cpp:332-388")
+    add("fbw_u32_all_100", fbw([100] * 100, U32, 8, base=100), U32, [100] * 100,
+        source="FixedBitWidthEncodingTest.cpp:332-388")
+    quad = [(i + i * i) % 1024 for i in range(10000)]
+    add("fba_10bit_quadratic", fbw(quad, U32, 10), U32, quad, source="common/tests/FixedBitArrayTests.cpp:27-39")
+    desc = [100 - i for i in range(27)]
+    add("fba_7bit_descending", fbw(desc, U32, 7), U32, desc, source="common/tests/FixedBitArrayTests.cpp:151-170")
+    add("fba_7bit_descending_into64", fbw(desc, U64, 7), U64, desc,
+        source="common/tests/FixedBitArrayTests.cpp:165-169 (bulkGet32Into64)")
+    wide = [(0x9E3779B97F4A7C15 * (i + 1)) & ((1 << 59) - 1) for i in range(300)]
+    add("fbw_u64_59bit_two_word_stitch", fbw(wide, U64, 59), U64, wide,
+        source="common/FixedBitArray.cpp:490-507 (widths 59..63 cross a word)")
+    wide58 = [v & ((1 << 58) - 1) for v in wide]
+    add("fbw_u64_58bit_boundary", fbw(wide58, U64, 58), U64, wide58,
+        source="common/tests/FixedBitArrayTests.cpp:459-479 (58-bit boundary)")
+    add("fbw_i64_baseline_12345", fbw([12345 + (i * 37) % 1000 for i in range(200)], I64, 16, base=12345), I64,
+        [12345 + (i * 37) % 1000 for i in range(200)], source="encodings/benchmarks/FixedBitWidthBenchmark.cpp:40")
+    add("trivial_i32", trivial([1, -2, 3, -4, 2**31 - 1, -2**31], I32), I32, [1, -2, 3, -4, 2**31 - 1, -2**31],
+        source="encodings/TrivialEncoding.h:40-44")
+    bools = [bool((i * 7) % 3 == 0) for i in range(75)]
+    add("trivial_bool_75", trivial(bools, BOOL), BOOL, bools, source="encodings/TrivialEncoding.h:191-194")
+    strs = [b"", b"a", b"nimble", b"\x00\xff", b"cascading stream encodings", b""]
+    add("trivial_string", trivial(strs, STR), STR, strs, source="encodings/TrivialEncoding.h:105-110")
+    add("rle_i32_233", rle([2, 3, 3], I32), I32, [2, 3, 3], source="encodings/tests/RLEEncodingTest.cpp:142-148")
+    tri = [1, 2, 2, 3, 3, 3, 4, 4, 4, 4]
+    add("rle_i32_triangle", rle(tri, I32), I32, tri, source="encodings/tests/RLEEncodingTest.cpp:142-148")
+    add("rle_i64_triangle_fbw_children", rle(tri, I64, child=lambda v, dt, vr=False: fbw(v, dt, 8, vr=vr)), I64, tri,
+        source="encodings/RLEEncoding.h:102-106,428-431")
+    f32 = [0x00000000, 0x80000000, 0x7FC00000, 0x7FA00000, 0x7FC00003, 0x7FC00005]
+    rl_f32 = [v for v in f32 for _ in range(3)]
+    add("rle_f32_zero_signs_and_nan_payloads", rle(rl_f32, F32), F32, rl_f32,
+        source="encodings/tests/RLEEncodingTest.cpp:172-195 (+-0.0 and NaN payloads survive bit-exactly)")
+    rb = [True] * 3 + [False] * 5 + [True] + [False] * 2
+    add("rle_bool", rle(rb, BOOL), BOOL, rb, source="encodings/RLEEncoding.h:741-745, RLEEncoding.cpp:39-46")
+    dv = [7, 7, 3, 9, 3, 7, 9, 9, 1]
+    add("dictionary_i32", dictionary(dv, I32), I32, dv, source="encodings/DictionaryEncoding.h:41-45,432-456")
+    ds = [b"x", b"yy", b"x", b"", b"yy", b"zzz"]
+    add("dictionary_string", dictionary(ds, STR), STR, ds, source="encodings/DictionaryEncoding.h:41-45")
+    sb = [False] * 40
+    for i in (3, 17, 18, 39):
+        sb[i] = True
+    add("sparse_bool_few_set", sparse_bool(sb), BOOL, sb, source="encodings/SparseBoolEncoding.cpp:190-217")
+    sb2 = [not b for b in sb]
+    add("sparse_bool_few_unset", sparse_bool(sb2), BOOL, sb2, source="encodings/SparseBoolEncoding.cpp:190-217")
+    add("constant_i64", constant(-5, 33, I64), I64, [-5] * 33, source="encodings/ConstantEncoding.h:33-35")
+    add("constant_string", constant(b"same", 4, STR), STR, [b"same"] * 4, source="encodings/ConstantEncoding.cpp:21-33")
+    add("constant_bool", constant(True, 9, BOOL), BOOL, [True] * 9, source="encodings/ConstantEncoding.h:305-326")
+    vv = [0, 1, 127, 128, 300, 16383, 16384, 2**21, 2**28 - 1, 2**28, 2**32 - 1]
+    add("varint_u32", varint_enc(vv, U32, base=0), U32, vv, source="common/Varint.h:70-102")
+    vv64 = vv + [2**35, 2**42 + 5, 2**49, 2**56 - 1, 2**63, 2**64 - 1]
+    add("varint_u64", varint_enc(vv64, U64, base=0), U64, vv64, source="common/Varint.h:104-143")
+    add("varint_i64_baseline", varint_enc([1000 + v for v in vv], I64, base=1000), I64, [1000 + v for v in vv],
+        source="encodings/VarintEncoding.h:37-40,132-138")
+    # Nullable{Dictionary, Trivial<bool>}: EncodingTest.cpp:1057-1115
+    mask = [True, False, True, True, False, False, True, True, True, False]
+    nn = [5, 6, 5, 7, 6, 5]
+    full = []
+    it = iter(nn)
+    for m in mask:
+        full.append(next(it) if m else 0)
+    add("nullable_dictionary_i32", nullable(dictionary(nn, I32), mask, I32), I32, full, nulls=mask,
+        source="encodings/tests/EncodingTest.cpp:1057-1115")
+    add("nullable_all_null", nullable(trivial([], I64), [False] * 5, I64), I64, [0] * 5, nulls=[False] * 5,
+        source="encodings/NullableEncoding.h:207-236")
+    add("nullable_no_nulls_sparse", nullable(fbw(r10, I16, 8), [True] * 10, I16, nulls_enc=sparse_bool([True] * 10)), I16, r10,
+        nulls=[True] * 10, source="encodings/NullableEncoding.h:38-42")
+    # MainlyConstant{Trivial<bool>, Constant}: EncodingTest.cpp:1128-1205
+    mc = [4, 4, 9, 4, 4, 4, 9, 4]
+    add("mainly_constant_constant_others", mainly_constant(mc, I32, 4, constant(9, 2, I32)), I32, mc,
+        source="encodings/tests/EncodingTest.cpp:1128-1205")
+    mc2 = [1, 1, 2, 1, 3, 1, 1, 9, 1, 1, 1]
+    add("mainly_constant_dictionary_others", mainly_constant(mc2, I64, 1, dictionary([2, 3, 9], I64)), I64, mc2,
+        source="encodings/tests/EncodingTest.cpp:1207-1285")
+    others = [v for v in mc2 if v != 1]
+    add("mainly_constant_sparse_is_common",
+        mainly_constant(mc2, I64, 1, trivial(others, I64), is_common_enc=sparse_bool([v == 1 for v in mc2])), I64, mc2,
+        source="encodings/MainlyConstantEncoding.h:758-787 (SparseBool fast path)")
+    ms = [b"c", b"c", b"other", b"c"]
+    add("mainly_constant_string", mainly_constant(ms, STR, b"c", trivial([b"other"], STR)), STR, ms,
+        source="encodings/MainlyConstantEncoding.cpp:21-43")
+    # three levels: Nullable{MainlyConstant{Trivial<bool>, Dictionary}, Trivial<bool>}: EncodingTest.cpp:1295-1340
+    nn2 = [1, 1, 2, 1, 3, 1]
+    full2 = []
+    it = iter(nn2)
+    for m in mask[:9]:
+        full2.append(next(it) if m else 0)
+    add("nullable_mainly_constant_dictionary",
+        nullable(mainly_constant(nn2, I32, 1, dictionary([2, 3], I32)), mask[:9], I32), I32, full2, nulls=mask[:9],
+        source="encodings/tests/EncodingTest.cpp:1295-1340")
+    out = {"format": 1,
+           "note": "hand-assembled; regenerate with tests/golden/make_golden.py",
+           "chunk_header_size": 5,
+           "cases": CASES}
+    with open(os.path.join(HERE, "golden_v1.json"), "w") as f:
+        json.dump(out, f, indent=0)
+    print(f"wrote {len(CASES)} cases")
+
+
+if __name__ == "__main__":
+    main()

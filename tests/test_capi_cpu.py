@@ -1,0 +1,155 @@
+"""CPU: the C-ABI library loads, exports every symbol include/nimble_amd.h
+declares, plans batches (header walk only, no GPU call) and reports malformed
+or unsupported bytes the way the reference's constructors do."""
+import ctypes as C
+import os
+import re
+import struct
+
+import numpy as np
+import pytest
+
+from nimble_amd import capi
+from nimble_amd import encoder as E
+from nimble_amd import wire as W
+from nimble_amd.decoder import Plan
+
+from golden_util import load_cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "nimble_amd.h")).read()
+    # function declarations: a return type, then the name, then "("
+    declared = set(re.findall(r"^(?:nbl_status|void|const char\*)\s+(nbl_[a-z_]+)\s*\(", header, flags=re.M))
+    assert declared, "no declarations found"
+    lib = capi.lib()
+    for sym in sorted(declared):
+        assert hasattr(lib, sym), f"{sym} is declared in include/nimble_amd.h but not exported"
+    assert declared == set(capi.EXPORTED_SYMBOLS)
+    assert lib.nbl_build_arch() == b"gfx950"
+
+
+def test_no_oracle_in_product_path():
+    """The product package must not import, link or load anything under oracle/."""
+    pkg = os.path.join(ROOT, "nimble_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert not re.search(r"(import|from|include|CDLL|dlopen)[^\n]*oracle", text), f"{f} reaches into oracle/"
+
+
+def test_plan_layout_of_a_batch():
+    rng = np.random.default_rng(0)
+    v = rng.integers(0, 1000, 100_000).astype(np.int64)
+    runs = np.repeat(v[:3000], 30)
+    mask = rng.random(5000) < 0.8
+    encs = [
+        E.encode(E.FixedBitWidth(), v, W.INT64),
+        E.encode(E.RLE(), runs, W.INT64),
+        E.encode_nullable(E.Nullable(data=E.FixedBitWidth(), nulls=E.SparseBool()), v[: int(mask.sum())], mask, W.INT64),
+        E.encode(E.Trivial(), E.StringColumn.from_list([b"ab", b"", b"cde"]), W.STRING),
+        E.encode(E.Trivial(), rng.random(77) < 0.5, W.BOOL),
+    ]
+    p = Plan.from_encodings(encs)
+    info = p.info
+    assert info.n_chunks == 5 and info.n_nodes == 1 + 3 + 4 + 2 + 1
+    assert info.encoded_bytes == sum(len(e) for e in encs)
+    assert info.arena_bytes >= info.encoded_bytes + 16
+    assert info.total_rows == 100_000 + 90_000 + 5000 + 3 + 77
+    lay = p.layouts
+    assert (lay[0].rows, lay[0].elem_bytes, lay[0].nullable, lay[0].values_bytes) == (100_000, 8, 0, 800_000)
+    assert lay[2].nullable == 1 and lay[2].non_null_rows == int(mask.sum()) and lay[2].nulls_bytes == (5000 + 63) // 64 * 8
+    assert lay[3].data_type == W.STRING and lay[3].elem_bytes == 8 and lay[3].string_bytes >= 5
+    assert lay[4].data_type == W.BOOL and lay[4].values_bytes == 77
+    # outputs do not overlap and stay inside out_bytes
+    spans = []
+    for l in lay:
+        for off, size in ((l.values_offset, l.values_bytes), (l.nulls_offset, l.nulls_bytes), (l.string_offset, l.string_bytes)):
+            if size:
+                spans.append((off, off + size))
+    spans.sort()
+    for (a0, a1), (b0, b1) in zip(spans, spans[1:]):
+        assert a1 <= b0
+    assert spans[-1][1] <= info.out_bytes
+    launches = p.launches()
+    assert len(launches) == info.n_launches
+    assert sum(l[4] for l in launches) == info.encoded_bytes + info.decoded_bytes
+    levels = [l[3] for l in launches]
+    assert levels == sorted(levels)
+    p.close()
+
+
+def test_every_golden_vector_plans():
+    for case in load_cases():
+        p = Plan.from_encodings([case["enc"]], case["varint_rows"])
+        assert p.layouts[0].data_type == case["data_type"], case["name"]
+        exp = case["expected"]
+        n = exp[0].size if case["data_type"] == W.STRING else exp.size
+        assert p.layouts[0].rows == n
+        p.close()
+
+
+def _expect(exc, enc, match=None):
+    with pytest.raises(exc, match=match):
+        Plan.from_encodings([enc])
+
+
+def test_malformed_and_unsupported_inputs():
+    ok = E.encode(E.Trivial(), np.arange(4, dtype=np.int32), W.INT32)
+    _expect(capi.NimbleCorruptError, bytes([99]) + ok[1:], "invalid EncodingType")        # EncodingFactory.cpp:158-162
+    _expect(capi.NimbleCorruptError, ok + b"\x00", "Unexpected trivial encoding end")       # TrivialEncoding.h:273-282
+    _expect(capi.NimbleCorruptError, ok[:-1], "Unexpected trivial encoding end")
+    _expect(capi.NimbleCorruptError, ok[:4], "prefix")
+    _expect(capi.NimbleUnsupportedError, ok[:6] + b"\x01" + ok[7:], "compressed")           # Zstd leaf payload
+    _expect(capi.NimbleUnsupportedError, bytes([8]) + ok[1:], "not decoded on the GPU")     # Delta
+    bad = bytearray(E.encode(E.SparseBool(), np.zeros(9, dtype=bool), W.BOOL))
+    bad[1] = W.INT32
+    _expect(capi.NimbleCorruptError, bytes(bad), "non-bool")                                # EncodingFactory.cpp:90-97
+    c = E.encode(E.Constant(), np.full(5, 3, dtype=np.int64), W.INT64)
+    _expect(capi.NimbleCorruptError, c + b"\x00", "Unexpected constant encoding end")       # ConstantEncoding.h:299-301
+    rb = E.encode(E.RLE(), np.array([1, 1, 0], dtype=bool), W.BOOL)
+    _expect(capi.NimbleCorruptError, rb + b"\x00", "Unexpected run length encoding end")    # RLEEncoding.cpp:30-35
+    f = bytearray(E.encode(E.FixedBitWidth(), np.arange(100, dtype=np.int32), W.INT32))
+    f[6 + 1 + 4] = 40
+    _expect(capi.NimbleCorruptError, bytes(f), "bit width")                                 # FixedBitArray.cpp:311-313
+    _expect(capi.NimbleCorruptError, E.encode(E.FixedBitWidth(), np.arange(100, dtype=np.int32), W.INT32)[:-20], "truncated")
+    # Nullable whose nulls child has another row count (NullableEncoding.h:169-170)
+    mask = np.array([True, False, True])
+    n = bytearray(E.encode_nullable(E.Nullable(), np.array([1, 2], dtype=np.int32), mask, W.INT32))
+    n[2:6] = struct.pack("<I", 4)
+    _expect(capi.NimbleCorruptError, bytes(n), "Nulls count mismatch")
+    # child size field pointing past the parent
+    r = bytearray(E.encode(E.RLE(), np.array([5, 5, 6], dtype=np.int32), W.INT32))
+    r[6:10] = struct.pack("<I", 10_000)
+    _expect(capi.NimbleCorruptError, bytes(r), "beyond end")
+
+
+def test_split_stream():
+    e1 = E.encode(E.Trivial(), np.arange(5, dtype=np.int32), W.INT32)
+    e2 = E.encode(E.FixedBitWidth(), np.arange(9, dtype=np.int64), W.INT64)
+    s = E.stream([e1, e2])
+    assert capi.split_stream(s) == [(5, len(e1)), (5 + len(e1) + 5, len(e2))]
+    assert capi.split_stream(b"") == []
+    with pytest.raises(capi.NimbleCorruptError, match="Read beyond end of stream"):
+        capi.split_stream(s[:-1])
+    with pytest.raises(capi.NimbleUnsupportedError):
+        capi.split_stream(E.chunk(e1, compression=W.ZSTD))
+    with pytest.raises(capi.NimbleCorruptError, match="Unexpected stream compression type"):
+        capi.split_stream(E.chunk(e1, compression=7))
+
+
+def test_decode_without_gpu_fails_loudly():
+    """No CPU fallback: without a device the decode entry point must report an error."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from nimble_amd.decoder import BatchDecoder
+
+    p = Plan.from_encodings([E.encode(E.Trivial(), np.arange(4, dtype=np.int32), W.INT32)])
+    with pytest.raises(RuntimeError):
+        BatchDecoder(p)
+    p.close()

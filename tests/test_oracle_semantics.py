@@ -1,0 +1,180 @@
+"""CPU: the oracle honours the reference's Encoding contract (row cursor,
+skip/reset, scattered materializeNullable) and ChunkedStreamDecoder stitching.
+Mirrors encodings/tests/EncodingTest.cpp:514-540,682-1021 and
+velox/tests/ChunkedStreamDecoderTest.cpp:175-259."""
+import numpy as np
+import pytest
+
+from nimble_amd import encoder as E
+from nimble_amd import wire as W
+
+from encoding_contract import check_materialize_patterns, check_nullable_scattered, check_scattered_materialize
+from util import ALL_NUMERIC, patterns, phys, random_data, random_strings, rle_data
+
+SPECS = {
+    "trivial": E.Trivial(), "fbw": E.FixedBitWidth(), "fbw_exact": E.FixedBitWidth(exact_bits=True), "rle": E.RLE(),
+    "dictionary": E.Dictionary(), "mainly_constant": E.MainlyConstant(), "varint": E.Varint(),
+    "mc_bitmap": E.MainlyConstant(is_common=E.Trivial(), other=E.FixedBitWidth()),
+}
+
+
+@pytest.mark.parametrize("varint_rows", [False, True])
+@pytest.mark.parametrize("dtype", ALL_NUMERIC)
+def test_numeric_contract(oracle, dtype, varint_rows):
+    rng = np.random.default_rng(1000 + dtype)
+    for n in (1, 33, 700):
+        for pname, data in patterns(rng, dtype, n):
+            for sname, spec in SPECS.items():
+                if sname == "varint" and W.elem_bytes(dtype) < 4:
+                    continue
+                enc = E.encode(spec, data, dtype, varint_rows)
+                e = oracle.Encoding(enc, varint_rows)
+                assert e.row_count == n and e.data_type == dtype
+                check_materialize_patterns(e, phys(data, dtype), dtype, rng)
+                e.reset()
+                check_scattered_materialize(e, phys(data, dtype), dtype, rng)
+            if pname == "constant":
+                e = oracle.Encoding(E.encode(E.Constant(), data, dtype, varint_rows), varint_rows)
+                check_materialize_patterns(e, phys(data, dtype), dtype, rng)
+
+
+def test_bool_contract(oracle):
+    rng = np.random.default_rng(5)
+    for n in (1, 64, 65, 500):
+        for p in (0.05, 0.5, 0.95):
+            b = rng.random(n) < p
+            for spec in (E.Trivial(), E.SparseBool(), E.RLE()):
+                e = oracle.Encoding(E.encode(spec, b, W.BOOL))
+                check_materialize_patterns(e, b.astype(np.uint8), W.BOOL, rng)
+                e.reset()
+                check_scattered_materialize(e, b.astype(np.uint8), W.BOOL, rng)
+                # materializeBoolsAsBits at an arbitrary bit offset, in two pieces
+                e.reset()
+                words = np.zeros((n + 70) // 64 + 2, dtype=np.uint64)
+                begin = 5
+                e.materialize_bools_as_bits(n // 2, words, begin)
+                e.materialize_bools_as_bits(n - n // 2, words, begin + n // 2)
+                bits = np.unpackbits(words.view(np.uint8), bitorder="little")[begin:begin + n].astype(bool)
+                assert np.array_equal(bits, b)
+
+
+def test_string_contract(oracle):
+    rng = np.random.default_rng(6)
+    for n in (1, 50, 400):
+        col = random_strings(rng, n)
+        alpha = random_strings(rng, 17)
+        picked = alpha.take(rng.integers(0, 17, n))
+        runs = alpha.take(np.sort(rng.integers(0, 17, n)))
+        for spec, c in ((E.Trivial(), col), (E.Dictionary(), picked), (E.RLE(values=E.Trivial()), runs),
+                        (E.MainlyConstant(other=E.Trivial()), picked), (E.Constant(), alpha.take(np.zeros(n, dtype=np.int64)))):
+            e = oracle.Encoding(E.encode(spec, c, W.STRING))
+            check_materialize_patterns(e, (c.lengths, c.blob), W.STRING, rng)
+
+
+@pytest.mark.parametrize("dtype", [W.INT32, W.INT64, W.DOUBLE, W.UINT8])
+def test_nullable_contract(oracle, dtype):
+    rng = np.random.default_rng(77 + dtype)
+    for n in (1, 10, 333):
+        for p_null in (0.0, 0.2, 0.8, 1.0):
+            mask = rng.random(n) >= p_null
+            vals = rle_data(rng, dtype, int(mask.sum())) if mask.any() else random_data(rng, dtype, 0)
+            for spec in (E.Nullable(data=E.Trivial(), nulls=E.Trivial()), E.Nullable(data=E.FixedBitWidth(), nulls=E.SparseBool()),
+                         E.Nullable(data=E.RLE(), nulls=E.RLE())):
+                enc = E.encode_nullable(spec, vals, mask, dtype)
+                e = oracle.Encoding(enc)
+                assert e.is_nullable and e.null_count == n - int(mask.sum())
+                check_nullable_scattered(e, phys(vals, dtype), mask, rng)
+                # Encoding::materialize zero-fills null rows
+                e.reset()
+                want = np.zeros(n, dtype=W.physical_dtype(dtype))
+                want[mask] = phys(vals, dtype)
+                assert np.array_equal(e.materialize(n), want)
+
+
+def _make_stream(rng, dtype, with_nulls):
+    """1..10 chunks of 1..10 rows, some nullable (ChunkedStreamDecoderTest.cpp:189-209)."""
+    chunks, values, masks = [], [], []
+    for _ in range(int(rng.integers(1, 11))):
+        n = int(rng.integers(1, 11))
+        nullable = with_nulls and bool(rng.integers(0, 2))
+        mask = (rng.random(n) < 0.6) if nullable else np.ones(n, dtype=bool)
+        v = random_data(rng, dtype, int(mask.sum()))
+        if nullable:
+            chunks.append(E.encode_nullable(E.Nullable(data=E.Trivial(), nulls=E.Trivial()), v, mask, dtype))
+        else:
+            chunks.append(E.encode(E.Trivial(), v, dtype))
+        full = np.zeros(n, dtype=W.physical_dtype(dtype))
+        full[mask] = phys(v, dtype)
+        values.append(full)
+        masks.append(mask)
+    return E.stream(chunks), np.concatenate(values), np.concatenate(masks)
+
+
+@pytest.mark.parametrize("with_nulls", [False, True])
+def test_stream_decoder_batches(oracle, with_nulls):
+    """Every batch size 1..total with reset() between iterations; dense reads."""
+    rng = np.random.default_rng(31 + with_nulls)
+    for _ in range(10):
+        stream, values, mask = _make_stream(rng, W.INT32, with_nulls)
+        total = values.size
+        d = oracle.StreamDecoder(stream)
+        for batch in range(1, total + 1):
+            d.reset()
+            pos = 0
+            while pos < total:
+                n = min(batch, total - pos)
+                out = np.zeros(n, dtype=np.uint32)
+                nulls = np.zeros((n + 7) // 8 + 8, dtype=np.uint8)
+                nn, requested = d.next(n, out, nulls)
+                m = mask[pos:pos + n]
+                assert nn == int(m.sum())
+                if nn != n:
+                    assert requested
+                    assert np.array_equal(np.unpackbits(nulls, bitorder="little")[:n].astype(bool), m)
+                assert np.array_equal(out[m], values[pos:pos + n][m])
+                pos += n
+
+
+def test_stream_decoder_skip_and_scatter(oracle):
+    rng = np.random.default_rng(8)
+    for _ in range(20):
+        stream, values, mask = _make_stream(rng, W.INT64, True)
+        total = values.size
+        d = oracle.StreamDecoder(stream)
+        skip = int(rng.integers(0, total))
+        d.skip(skip)
+        n = total - skip
+        scatter = []
+        while sum(scatter) < n:
+            scatter.append(bool(rng.integers(0, 2)))
+        scatter = np.array(scatter, dtype=bool)
+        sbits = np.zeros((scatter.size + 7) // 8 + 8, dtype=np.uint8)
+        sbits[:(scatter.size + 7) // 8] = np.packbits(scatter.astype(np.uint8), bitorder="little")
+        out = np.zeros(scatter.size, dtype=np.uint64)
+        nulls = np.zeros((scatter.size + 7) // 8 + 8, dtype=np.uint8)
+        nn, requested = d.next(n, out, nulls, sbits, scatter.size)
+        m = mask[skip:]
+        assert nn == int(m.sum())
+        slots = np.flatnonzero(scatter)[m]
+        assert np.array_equal(out[slots], values[skip:][m])
+        if nn != scatter.size:
+            want = np.zeros(scatter.size, dtype=bool)
+            want[slots] = True
+            assert np.array_equal(np.unpackbits(nulls, bitorder="little")[:scatter.size].astype(bool), want)
+
+
+def test_split_stream_and_errors(oracle):
+    s = E.stream([E.encode(E.Trivial(), np.arange(5, dtype=np.int32), W.INT32),
+                  E.encode(E.Trivial(), np.arange(3, dtype=np.int32), W.INT32)])
+    parts = oracle.split_stream(s)
+    assert [sz for _, sz in parts] == [6 + 1 + 20, 6 + 1 + 12] and parts[0][0] == 5
+    with pytest.raises(oracle.OracleError):
+        oracle.split_stream(s[:-1])
+    with pytest.raises(oracle.OracleError):
+        oracle.Encoding(bytes([99, 5, 1, 0, 0, 0, 0]))
+    with pytest.raises(oracle.OracleError):  # trailing garbage after a Trivial payload
+        oracle.Encoding(E.encode(E.Trivial(), np.arange(4, dtype=np.int32), W.INT32) + b"\x00")
+    with pytest.raises(oracle.OracleError):  # SparseBool with a non-bool type (EncodingFactory.cpp:90-97)
+        bad = bytearray(E.encode(E.SparseBool(), np.zeros(9, dtype=bool), W.BOOL))
+        bad[1] = W.INT32
+        oracle.Encoding(bytes(bad))
