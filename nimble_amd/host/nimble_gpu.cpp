@@ -1,0 +1,396 @@
+// GPU-backed Encoding / EncodingFactory / Decoder (see nimble_gpu.h).
+#include "nimble_gpu.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+
+namespace nimble_amd {
+
+namespace {
+
+[[noreturn]] void throwStatus(int st) {
+  const std::string msg = nbl_last_error();
+  if (st == NBL_ERR_UNSUPPORTED) throw NimbleUnsupported(st, msg);
+  throw NimbleError(st, msg);
+}
+void check(int st) {
+  if (st != NBL_OK) throwStatus(st);
+}
+void hipCheck(hipError_t e, const char* what) {
+  if (e != hipSuccess) throw NimbleError(NBL_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+inline bool bitIsSet(const void* bits, uint64_t i) { return (static_cast<const uint8_t*>(bits)[i >> 3] >> (i & 7)) & 1; }
+inline void bitSet(void* bits, uint64_t i) { static_cast<uint8_t*>(bits)[i >> 3] |= uint8_t(1u << (i & 7)); }
+inline void bitClear(void* bits, uint64_t i) { static_cast<uint8_t*>(bits)[i >> 3] &= uint8_t(~(1u << (i & 7))); }
+void fillBits(void* bits, uint64_t begin, uint64_t end, bool v) {
+  for (uint64_t i = begin; i < end; ++i) v ? bitSet(bits, i) : bitClear(bits, i);
+}
+uint32_t countBits(const void* bits, uint64_t begin, uint64_t end) {
+  uint32_t n = 0;
+  for (uint64_t i = begin; i < end; ++i) n += bitIsSet(bits, i);
+  return n;
+}
+// velox::bits::findSetBit: position of the n-th (1-based) set bit in [begin,end), `end` if fewer.
+uint32_t findSetBit(const void* bits, uint32_t begin, uint32_t end, uint32_t n) {
+  uint32_t seen = 0;
+  for (uint32_t i = begin; i < end; ++i)
+    if (bitIsSet(bits, i) && ++seen == n) return i;
+  return end;
+}
+
+struct DeviceBuffer {
+  void* ptr = nullptr;
+  size_t cap = 0;
+  void reserve(size_t n) {
+    if (n <= cap) return;
+    if (ptr) hipCheck(hipFree(ptr), "hipFree");
+    ptr = nullptr;
+    cap = 0;
+    const size_t want = std::max<size_t>(n, 1 << 20);
+    hipCheck(hipMalloc(&ptr, want), "hipMalloc");
+    cap = want;
+  }
+  ~DeviceBuffer() {
+    if (ptr) (void)hipFree(ptr);
+  }
+};
+
+}  // namespace
+
+class GpuContext {
+ public:
+  explicit GpuContext(int device) : device_(device) {}
+  ~GpuContext() {
+    if (stream_) (void)hipStreamDestroy(stream_);
+  }
+  std::mutex mu;
+  int device_;
+  hipStream_t stream_ = nullptr;
+  DeviceBuffer arena, out, work;
+  void ensure() {
+    hipCheck(hipSetDevice(device_), "hipSetDevice");
+    if (!stream_) hipCheck(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+  }
+};
+
+namespace {
+
+// One decoded chunk resident in host memory.
+class GpuEncoding final : public Encoding {
+ public:
+  GpuEncoding(const nbl_chunk_layout& lay, const uint8_t* hostOut, const GpuEncodingFactory::StringBufferFactory& sbf)
+      : lay_(lay) {
+    es_ = lay.elem_bytes;
+    values_.assign(hostOut + lay.values_offset, hostOut + lay.values_offset + lay.values_bytes);
+    if (lay.nullable) nulls_.assign(hostOut + lay.nulls_offset, hostOut + lay.nulls_offset + lay.nulls_bytes);
+    if (lay.data_type == (uint8_t)DataType::String) {
+      // string bytes live in memory the caller's factory hands out, as the
+      // reference's string encodings do (TrivialEncoding.cpp:129-135)
+      char* dst = lay.string_bytes ? static_cast<char*>(sbf(static_cast<uint32_t>(lay.string_bytes))) : nullptr;
+      if (lay.string_bytes) memcpy(dst, hostOut + lay.string_offset, lay.string_bytes);
+      strings_ = dst;
+      const uint64_t* views = reinterpret_cast<const uint64_t*>(values_.data());
+      for (uint32_t i = 0; i < lay.rows; ++i) {
+        const uint64_t off = views[i] & 0xFFFFFFFFull, len = views[i] >> 32;
+        if (off + len > lay.string_bytes) throw NimbleError(NBL_ERR_DEVICE_DATA, "string view outside the string buffer");
+      }
+    }
+  }
+  EncodingType encodingType() const override { return static_cast<EncodingType>(lay_.encoding_type); }
+  DataType dataType() const override { return static_cast<DataType>(lay_.data_type); }
+  uint32_t rowCount() const override { return lay_.rows; }
+  uint32_t nullCount() const override { return lay_.rows - lay_.non_null_rows; }
+  bool isNullable() const override { return lay_.nullable != 0; }
+  void reset() override { row_ = 0; }
+  void skip(uint32_t n) override { advance(n); }
+
+  void materialize(uint32_t n, void* buffer) override {
+    const uint32_t r = advance(n);
+    copyRows(r, n, buffer, 0);
+  }
+
+  uint32_t materializeNullable(uint32_t n, void* buffer, std::function<void*()> getOutputNulls, const Bitmap* scatter,
+                               uint32_t offset) override {
+    const uint32_t r = advance(n);
+    const uint32_t scatterSize = scatter ? scatter->size - offset : n;
+    if (scatterSize < n) throw NimbleError(NBL_ERR_ARGUMENT, "Scattered output must have at least rowCount positions");
+    if (!lay_.nullable) {  // TypedEncoding::materializeNullable, Encoding.h:412-460
+      if (scatterSize == n) {
+        copyRows(r, n, buffer, offset);
+        return n;
+      }
+      void* nulls = getOutputNulls();
+      uint32_t src = r;
+      for (uint32_t pos = offset; pos < offset + scatterSize; ++pos) {
+        if (scatter->test(pos)) {
+          bitSet(nulls, pos);
+          if (src < r + n) copyRows(src++, 1, buffer, pos);
+        } else {
+          bitClear(nulls, pos);
+        }
+      }
+      return n;
+    }
+    // NullableEncoding::materializeNullable, NullableEncoding.h:239-306
+    const uint32_t nonNull = countBits(nulls_.data(), r, (uint64_t)r + n);
+    if (nonNull == scatterSize) {  // no nulls in range and no gaps: bitmap untouched
+      copyRows(r, n, buffer, offset);
+      return nonNull;
+    }
+    void* nulls = getOutputNulls();
+    fillBits(nulls, offset, (uint64_t)offset + scatterSize, false);
+    uint32_t src = r;
+    for (uint32_t pos = offset; pos < offset + scatterSize && src < r + n; ++pos) {
+      if (scatter && !scatter->test(pos)) continue;
+      if (bitIsSet(nulls_.data(), src)) {
+        bitSet(nulls, pos);
+        copyRows(src, 1, buffer, pos);
+      }
+      ++src;
+    }
+    return nonNull;
+  }
+
+  void materializeBoolsAsBits(uint32_t n, uint64_t* buffer, int begin) override {
+    if (lay_.data_type != (uint8_t)DataType::Bool) throw NimbleError(NBL_ERR_ARGUMENT, "materializeBoolsAsBits on a non-bool encoding");
+    const uint32_t r = advance(n);
+    for (uint32_t i = 0; i < n; ++i) values_[r + i] ? bitSet(buffer, (uint64_t)begin + i) : bitClear(buffer, (uint64_t)begin + i);
+  }
+
+ private:
+  uint32_t advance(uint32_t n) {
+    if ((uint64_t)row_ + n > lay_.rows) throw NimbleError(NBL_ERR_ARGUMENT, "read past the end of the encoding");
+    const uint32_t r = row_;
+    row_ += n;
+    return r;
+  }
+  // rows [r, r+n) of the decoded chunk -> slots [slot, slot+n) of `buffer`
+  void copyRows(uint32_t r, uint32_t n, void* buffer, uint32_t slot) const {
+    if (lay_.data_type == (uint8_t)DataType::String) {
+      auto* out = static_cast<std::string_view*>(buffer) + slot;
+      const uint64_t* views = reinterpret_cast<const uint64_t*>(values_.data());
+      for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t v = views[r + i];
+        out[i] = std::string_view(strings_ + (v & 0xFFFFFFFFull), static_cast<size_t>(v >> 32));
+      }
+    } else {
+      memcpy(static_cast<uint8_t*>(buffer) + (size_t)slot * es_, values_.data() + (size_t)r * es_, (size_t)n * es_);
+    }
+  }
+
+  nbl_chunk_layout lay_;
+  uint32_t es_ = 0;
+  uint32_t row_ = 0;
+  std::vector<uint8_t> values_;
+  std::vector<uint8_t> nulls_;
+  const char* strings_ = nullptr;
+};
+
+struct PlanHolder {
+  nbl_plan* p = nullptr;
+  ~PlanHolder() { nbl_plan_free(p); }
+};
+
+// plan + H2D + decode + D2H for chunks given as (pointer, size) pairs.
+std::vector<std::unique_ptr<Encoding>> decodeChunks(GpuContext& ctx, const std::vector<std::string_view>& chunks,
+                                                    const GpuEncodingFactory::StringBufferFactory& sbf, const Options& opts) {
+  std::vector<std::unique_ptr<Encoding>> result;
+  if (chunks.empty()) return result;
+  // the C ABI wants one base pointer: address chunks relative to the lowest one
+  // when they share a buffer closely, otherwise pack them into a staging buffer
+  std::vector<uint8_t> staging;
+  std::vector<uint64_t> offs(chunks.size()), sizes(chunks.size());
+  uint64_t pos = 0;
+  for (size_t i = 0; i < chunks.size(); ++i) {
+    offs[i] = pos;
+    sizes[i] = chunks[i].size();
+    pos += (chunks[i].size() + 15) & ~uint64_t(15);
+  }
+  staging.resize(pos);
+  for (size_t i = 0; i < chunks.size(); ++i) memcpy(staging.data() + offs[i], chunks[i].data(), chunks[i].size());
+
+  nbl_options o{sizeof(nbl_options), opts.useVarintRowCount ? 1u : 0u};
+  PlanHolder plan;
+  check(nbl_plan_batch(staging.data(), offs.data(), sizes.data(), (uint32_t)chunks.size(), &o, &plan.p));
+  nbl_plan_info info;
+  check(nbl_plan_get_info(plan.p, &info));
+
+  std::vector<uint8_t> hostOut(info.out_bytes);
+  {
+    std::lock_guard<std::mutex> lock(ctx.mu);
+    ctx.ensure();
+    ctx.arena.reserve(info.arena_bytes);
+    ctx.out.reserve(info.out_bytes);
+    ctx.work.reserve(info.work_bytes);
+    hipCheck(hipMemcpyAsync(ctx.arena.ptr, staging.data(), staging.size(), hipMemcpyHostToDevice, ctx.stream_), "H2D");
+    check(nbl_plan_upload(plan.p, ctx.work.ptr, ctx.stream_));
+    check(nbl_decode_batch_device(plan.p, ctx.arena.ptr, ctx.out.ptr, ctx.work.ptr, ctx.stream_));
+    hipCheck(hipMemcpyAsync(hostOut.data(), ctx.out.ptr, info.out_bytes, hipMemcpyDeviceToHost, ctx.stream_), "D2H");
+    check(nbl_decode_status(plan.p, ctx.work.ptr, ctx.stream_));  // synchronises the stream
+  }
+  result.reserve(chunks.size());
+  for (uint32_t c = 0; c < chunks.size(); ++c) {
+    nbl_chunk_layout lay;
+    check(nbl_plan_get_chunk_layout(plan.p, c, &lay));
+    result.push_back(std::make_unique<GpuEncoding>(lay, hostOut.data(), sbf));
+  }
+  return result;
+}
+
+}  // namespace
+
+GpuEncodingFactory::GpuEncodingFactory(Options options, int device)
+    : options_(options), ctx_(std::make_shared<GpuContext>(device)) {}
+GpuEncodingFactory::~GpuEncodingFactory() = default;
+
+std::unique_ptr<Encoding> GpuEncodingFactory::create(std::string_view data, StringBufferFactory sbf) const {
+  return create(data, std::move(sbf), options_);
+}
+
+std::unique_ptr<Encoding> GpuEncodingFactory::create(std::string_view data, StringBufferFactory sbf, const Options& options) const {
+  try {
+    auto v = decodeChunks(*ctx_, {data}, sbf, options);
+    return std::move(v[0]);
+  } catch (const NimbleUnsupported&) {
+    if (fallback_) return fallback_(data, sbf);
+    throw;
+  }
+}
+
+std::vector<std::unique_ptr<Encoding>> GpuEncodingFactory::createBatch(const std::vector<std::string_view>& chunks,
+                                                                       StringBufferFactory sbf, const Options& options) const {
+  try {
+    return decodeChunks(*ctx_, chunks, sbf, options);
+  } catch (const NimbleUnsupported&) {
+    if (!fallback_) throw;
+  }
+  // some chunk needs the CPU factory: decode one by one so only that chunk falls back
+  std::vector<std::unique_ptr<Encoding>> out;
+  for (auto c : chunks) out.push_back(create(c, sbf, options));
+  return out;
+}
+
+// ------------------------------------------------------------ stripe decoder
+namespace {
+
+class GpuStreamDecoder final : public Decoder {
+ public:
+  std::vector<std::unique_ptr<Encoding>> chunks;           // decoded up front by the stripe batch
+  std::vector<std::shared_ptr<void>> strings;               // keeps the string bytes of chunk i alive
+
+  uint32_t next(uint32_t count, void* output, std::vector<std::shared_ptr<void>>& stringBuffers,
+                std::function<void*()> getOutputNulls, const Bitmap* scatter) override {
+    // ChunkedStreamDecoder::next, velox/ChunkedStreamDecoder.cpp:75-176
+    if (count == 0) {
+      if (getOutputNulls && scatter) memset(getOutputNulls(), 0, (scatter->size + 7) / 8);
+      return 0;
+    }
+    uint32_t nonNullCount = 0, offset = 0;
+    bool hasNulls = false;
+    void* nullsPtr = nullptr;
+    std::function<void*()> initNulls = [&]() {
+      if (!nullsPtr) nullsPtr = getOutputNulls();
+      return nullsPtr;
+    };
+    while (count > 0) {
+      ensureLoaded();
+      Encoding& enc = *chunks[cur_];
+      const uint32_t rows = std::min(count, remaining_);
+      uint32_t chunkNonNull = 0, endOffset = 0;
+      if (!getOutputNulls || !scatter) {
+        if (scatter) throw NimbleError(NBL_ERR_ARGUMENT, "Unexpected scatter output bitmap");
+        chunkNonNull = enc.materializeNullable(rows, output, initNulls, nullptr, offset);
+        endOffset = offset + rows;
+      } else {
+        endOffset = findSetBit(scatter->bits, offset, scatter->size, rows + 1);
+        Bitmap local{scatter->bits, endOffset};
+        chunkNonNull = enc.materializeNullable(rows, output, initNulls, &local, offset);
+      }
+      const bool chunkHasNulls = chunkNonNull != endOffset - offset;
+      if (chunkHasNulls && !hasNulls) fillBits(nullsPtr, 0, offset, true);           // back-fill, :129-134
+      hasNulls = hasNulls || chunkHasNulls;
+      if (hasNulls && !chunkHasNulls) fillBits(nullsPtr, offset, endOffset, true);   // :136-140
+      offset = endOffset;
+      remaining_ -= rows;
+      count -= rows;
+      nonNullCount += chunkNonNull;
+      // every chunk's string bytes stay alive through the buffers handed back (:165-172)
+      if (cur_ < strings.size() && strings[cur_]) stringBuffers.push_back(strings[cur_]);
+    }
+    return nonNullCount;
+  }
+  void skip(uint32_t count) override {  // :178-186
+    while (count > 0) {
+      ensureLoaded();
+      const uint32_t n = std::min(count, remaining_);
+      chunks[cur_]->skip(n);
+      count -= n;
+      remaining_ -= n;
+    }
+  }
+  void reset() override {  // :188-191
+    next_ = 0;
+    remaining_ = 0;
+  }
+  const Encoding* encoding() const override { return cur_ < chunks.size() ? chunks[cur_].get() : nullptr; }
+
+ private:
+  void ensureLoaded() {  // :193-205
+    if (remaining_ != 0) return;
+    if (next_ >= chunks.size()) throw NimbleError(NBL_ERR_CORRUPT, "Read beyond end of stream");
+    cur_ = next_++;
+    chunks[cur_]->reset();
+    remaining_ = chunks[cur_]->rowCount();
+    if (remaining_ == 0) throw NimbleError(NBL_ERR_CORRUPT, "Empty chunk");
+  }
+  size_t cur_ = 0, next_ = 0;
+  uint32_t remaining_ = 0;
+};
+
+}  // namespace
+
+struct GpuStripeDecoder::Impl {
+  std::vector<std::unique_ptr<GpuStreamDecoder>> streams;
+};
+
+GpuStripeDecoder::GpuStripeDecoder(const GpuEncodingFactory& factory, const std::vector<std::string_view>& streams)
+    : impl_(std::make_unique<Impl>()) {
+  std::vector<std::string_view> chunks;
+  std::vector<size_t> owner;
+  for (size_t s = 0; s < streams.size(); ++s) {
+    uint32_t n = 0;
+    const auto* p = reinterpret_cast<const uint8_t*>(streams[s].data());
+    check(nbl_split_stream(p, streams[s].size(), nullptr, nullptr, 0, &n));
+    std::vector<uint64_t> offs(n ? n : 1), sizes(n ? n : 1);
+    check(nbl_split_stream(p, streams[s].size(), offs.data(), sizes.data(), n, &n));
+    for (uint32_t i = 0; i < n; ++i) {
+      chunks.emplace_back(streams[s].data() + offs[i], sizes[i]);
+      owner.push_back(s);
+    }
+    impl_->streams.push_back(std::make_unique<GpuStreamDecoder>());
+  }
+  // String bytes of the whole batch live in buffers owned by one keep-alive
+  // object that every string chunk of every stream shares (coarser than the
+  // reference's per-chunk lifetime, never shorter).
+  auto keep = std::make_shared<std::vector<std::unique_ptr<char[]>>>();
+  auto sbf = [keep](uint32_t bytes) -> void* {
+    keep->push_back(std::make_unique<char[]>(bytes ? bytes : 1));
+    return keep->back().get();
+  };
+  auto encs = factory.createBatch(chunks, sbf, factory.options());
+  for (size_t c = 0; c < encs.size(); ++c) {
+    auto& sd = *impl_->streams[owner[c]];
+    const bool isString = encs[c]->dataType() == DataType::String;
+    sd.chunks.push_back(std::move(encs[c]));
+    sd.strings.push_back(isString ? std::shared_ptr<void>(keep, keep.get()) : std::shared_ptr<void>());
+  }
+}
+GpuStripeDecoder::~GpuStripeDecoder() = default;
+size_t GpuStripeDecoder::streamCount() const { return impl_->streams.size(); }
+Decoder& GpuStripeDecoder::decoder(size_t stream) { return *impl_->streams.at(stream); }
+
+}  // namespace nimble_amd

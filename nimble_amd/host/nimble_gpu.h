@@ -1,0 +1,156 @@
+// C++ host layer above the C ABI (include/nimble_amd.h): GPU-backed mirrors of
+// the reference's extension and reader interfaces for the cascaded-stream
+// decode path, with the same names, argument meaning and error behaviour:
+//
+//   nimble::Encoding ............ dwio/nimble/encodings/common/Encoding.h:110-389
+//   nimble::EncodingFactory ..... dwio/nimble/encodings/common/EncodingFactory.h:32-55
+//   nimble::Decoder ............. dwio/nimble/velox/Decoder.h:27-56
+//   ChunkedStreamDecoder ........ dwio/nimble/velox/ChunkedStreamDecoder.h:25-74
+//
+// Velox is not available to this build, so the two Velox types in those
+// signatures are replaced by the smallest equivalents: the MemoryPool argument
+// is dropped (host memory comes from the C++ allocator) and bits::Bitmap is the
+// two-field view below.  INTEGRATION.md shows the adapter a Nimble maintainer
+// adds to plug these classes into the real interfaces.
+#pragma once
+
+#include <cstdint>
+#include <functional>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <string_view>
+#include <vector>
+
+#include "nimble_amd.h"
+
+namespace nimble_amd {
+
+// Error convention of the reference (dwio/nimble/common/Exceptions.h:111-155):
+// malformed input and broken invariants throw.  `status` is the nbl_status.
+class NimbleError : public std::runtime_error {
+ public:
+  NimbleError(int status, const std::string& msg) : std::runtime_error(msg), status_(status) {}
+  int status() const { return status_; }
+
+ private:
+  int status_;
+};
+// Well-formed Nimble the GPU path does not handle (compressed payloads,
+// experimental encodings): the integration catches this and calls the CPU factory.
+class NimbleUnsupported : public NimbleError {
+ public:
+  using NimbleError::NimbleError;
+};
+
+// velox::bits::Bitmap stand-in: `size` bits at `bits`, LSB first.
+struct Bitmap {
+  const void* bits;
+  uint32_t size;
+  bool test(uint32_t pos) const { return (static_cast<const uint8_t*>(bits)[pos >> 3] >> (pos & 7)) & 1; }
+};
+
+enum class EncodingType : uint8_t {
+  Trivial = 0, RLE = 1, Dictionary = 2, FixedBitWidth = 3, Sentinel = 4, Nullable = 5, SparseBool = 6,
+  Varint = 7, Delta = 8, Constant = 9, MainlyConstant = 10
+};
+enum class DataType : uint8_t {
+  Undefined = 0, Int8 = 1, Uint8 = 2, Int16 = 3, Uint16 = 4, Int32 = 5, Uint32 = 6, Int64 = 7, Uint64 = 8,
+  Float = 9, Double = 10, Bool = 11, String = 12
+};
+
+// Encoding::Options fields that matter on the decode side (Encoding.h:115-175).
+struct Options {
+  bool useVarintRowCount = false;
+};
+
+// Same contract as nimble::Encoding: a row cursor over one decoded chunk.
+// materialize() writes physicalType[] (bool: one byte per row, string:
+// std::string_view[] into stringBufferFactory memory); null rows of a Nullable
+// chunk read as physicalType().  materializeNullable() leaves null slots
+// untouched, asks for the null bitmap only when the range has nulls (or a
+// scatter with gaps), returns the number of non-null rows.
+class Encoding {
+ public:
+  virtual ~Encoding() = default;
+  virtual EncodingType encodingType() const = 0;
+  virtual DataType dataType() const = 0;
+  virtual uint32_t rowCount() const = 0;
+  virtual uint32_t nullCount() const = 0;
+  virtual bool isNullable() const = 0;
+  virtual void reset() = 0;
+  virtual void skip(uint32_t rowCount) = 0;
+  virtual void materialize(uint32_t rowCount, void* buffer) = 0;
+  virtual uint32_t materializeNullable(uint32_t rowCount, void* buffer, std::function<void*()> getOutputNulls,
+                                       const Bitmap* scatterOutputBitmap = nullptr, uint32_t offset = 0) = 0;
+  virtual void materializeBoolsAsBits(uint32_t rowCount, uint64_t* buffer, int begin) = 0;
+};
+
+class GpuContext;  // device, stream and reusable device buffers
+
+// Mirror of nimble::EncodingFactory with the decode running on the GPU.  A
+// factory is const, shareable and re-entrant (one mutex around the device
+// buffers); each Encoding it returns is single-threaded and stateful.
+class GpuEncodingFactory {
+ public:
+  using StringBufferFactory = std::function<void*(uint32_t)>;
+  using Fallback = std::function<std::unique_ptr<Encoding>(std::string_view, StringBufferFactory)>;
+
+  explicit GpuEncodingFactory(Options options = {}, int device = 0);
+  virtual ~GpuEncodingFactory();
+
+  // EncodingFactory::create(pool, data, stringBufferFactory): plans, decodes and
+  // fetches the one chunk `data`.  The returned Encoding does not own `data`.
+  virtual std::unique_ptr<Encoding> create(std::string_view data, StringBufferFactory stringBufferFactory) const;
+  // The overload that takes per-call options (EncodingFactory.h:47-51).
+  virtual std::unique_ptr<Encoding> create(std::string_view data, StringBufferFactory stringBufferFactory,
+                                           const Options& options) const;
+  const Options& options() const { return options_; }
+  // Where unsupported-but-valid encodings go (the reference's CPU factory in a
+  // real integration).  Without one, NimbleUnsupported propagates.
+  void setFallback(Fallback fallback) { fallback_ = std::move(fallback); }
+
+  // Batch form: decodes many chunks with ONE plan / one set of launches and
+  // returns one Encoding per chunk.  This is what a stripe-level reader uses.
+  std::vector<std::unique_ptr<Encoding>> createBatch(const std::vector<std::string_view>& chunks,
+                                                     StringBufferFactory stringBufferFactory,
+                                                     const Options& options) const;
+
+ private:
+  Options options_;
+  Fallback fallback_;
+  std::shared_ptr<GpuContext> ctx_;
+};
+
+// nimble::Decoder (velox/Decoder.h:27-56) with std::vector<std::shared_ptr<void>>
+// standing in for the BufferPtr list that keeps string bytes alive.
+class Decoder {
+ public:
+  virtual ~Decoder() = default;
+  virtual uint32_t next(uint32_t count, void* output, std::vector<std::shared_ptr<void>>& stringBuffers,
+                        std::function<void*()> getOutputNulls = nullptr,
+                        const Bitmap* scatterOutputBitmap = nullptr) = 0;
+  virtual void skip(uint32_t count) = 0;
+  virtual void reset() = 0;
+  virtual const Encoding* encoding() const = 0;
+};
+
+// All streams of a stripe decoded in one batch; hands out one Decoder per
+// stream with ChunkedStreamDecoder semantics (velox/ChunkedStreamDecoder.cpp:75-205).
+// Mirrors VeloxReader::loadNextStripe creating every stream's decoder at once
+// (velox/VeloxReader.cpp:330-351).
+class GpuStripeDecoder {
+ public:
+  // `streams[i]` = the raw bytes of stream i (chunk headers included); the
+  // bytes must stay alive while the decoders are used.
+  GpuStripeDecoder(const GpuEncodingFactory& factory, const std::vector<std::string_view>& streams);
+  ~GpuStripeDecoder();
+  size_t streamCount() const;
+  Decoder& decoder(size_t stream);
+
+ private:
+  struct Impl;
+  std::unique_ptr<Impl> impl_;
+};
+
+}  // namespace nimble_amd

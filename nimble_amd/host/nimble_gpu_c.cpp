@@ -1,0 +1,157 @@
+// Flat C wrappers over the C++ host layer (nimble_gpu.h) so that the Python
+// tests can drive GpuEncodingFactory / Encoding / GpuStripeDecoder through
+// ctypes.  Every function returns 0 on success, non-zero on a thrown error
+// whose text nblh_last_error() then returns.
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "nimble_gpu.h"
+
+using namespace nimble_amd;
+
+namespace {
+thread_local std::string g_err;
+thread_local int g_status = 0;
+
+struct EncHandle {
+  std::unique_ptr<Encoding> enc;
+  std::vector<std::unique_ptr<char[]>> strings;  // stringBufferFactory memory
+};
+struct FactoryHandle {
+  std::unique_ptr<GpuEncodingFactory> f;
+};
+struct StripeHandle {
+  std::vector<std::string> streams;  // owned copies of the stream bytes
+  std::unique_ptr<GpuStripeDecoder> dec;
+};
+
+template <typename F>
+int guard(F&& f) {
+  try {
+    f();
+    g_status = 0;
+    return 0;
+  } catch (const NimbleError& e) {
+    g_err = e.what();
+    g_status = e.status();
+    return e.status() ? e.status() : -1;
+  } catch (const std::exception& e) {
+    g_err = e.what();
+    g_status = -1;
+    return -1;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+const char* nblh_last_error() { return g_err.c_str(); }
+
+void* nblh_factory_create(int use_varint_row_count, int device) {
+  FactoryHandle* h = nullptr;
+  guard([&] {
+    h = new FactoryHandle();
+    Options o;
+    o.useVarintRowCount = use_varint_row_count != 0;
+    h->f = std::make_unique<GpuEncodingFactory>(o, device);
+  });
+  return h;
+}
+void nblh_factory_free(void* f) { delete static_cast<FactoryHandle*>(f); }
+
+void* nblh_encoding_create(void* factory, const char* data, uint64_t size) {
+  EncHandle* h = new EncHandle();
+  const int rc = guard([&] {
+    auto sbf = [h](uint32_t bytes) -> void* {
+      h->strings.push_back(std::make_unique<char[]>(bytes ? bytes : 1));
+      return h->strings.back().get();
+    };
+    h->enc = static_cast<FactoryHandle*>(factory)->f->create(std::string_view(data, size), sbf);
+  });
+  if (rc != 0) {
+    delete h;
+    return nullptr;
+  }
+  return h;
+}
+void nblh_encoding_free(void* e) { delete static_cast<EncHandle*>(e); }
+
+static Encoding& E(void* e) { return *static_cast<EncHandle*>(e)->enc; }
+
+uint32_t nblh_row_count(void* e) { return E(e).rowCount(); }
+uint32_t nblh_null_count(void* e) { return E(e).nullCount(); }
+int nblh_is_nullable(void* e) { return E(e).isNullable(); }
+int nblh_data_type(void* e) { return (int)E(e).dataType(); }
+int nblh_encoding_type(void* e) { return (int)E(e).encodingType(); }
+int nblh_reset(void* e) { return guard([&] { E(e).reset(); }); }
+int nblh_skip(void* e, uint32_t n) { return guard([&] { E(e).skip(n); }); }
+int nblh_materialize(void* e, uint32_t n, void* buffer) { return guard([&] { E(e).materialize(n, buffer); }); }
+int nblh_materialize_bools_as_bits(void* e, uint32_t n, uint64_t* buffer, int begin) {
+  return guard([&] { E(e).materializeBoolsAsBits(n, buffer, begin); });
+}
+// *non_null receives the return value; *requested is set when getOutputNulls was called.
+int nblh_materialize_nullable(void* e, uint32_t n, void* buffer, void* nulls, int* requested, const void* scatter,
+                              uint32_t scatter_size, uint32_t offset, uint32_t* non_null) {
+  return guard([&] {
+    int req = 0;
+    Bitmap bm{scatter, scatter_size};
+    *non_null = E(e).materializeNullable(
+        n, buffer, [&]() { req = 1; return nulls; }, scatter ? &bm : nullptr, offset);
+    if (requested) *requested = req;
+  });
+}
+// std::string_view[n] -> lengths + concatenated bytes
+uint64_t nblh_sv_total(const void* sv, uint32_t n) {
+  uint64_t t = 0;
+  for (uint32_t i = 0; i < n; ++i) t += static_cast<const std::string_view*>(sv)[i].size();
+  return t;
+}
+void nblh_sv_flatten(const void* sv, uint32_t n, uint32_t* lengths, char* bytes) {
+  uint64_t off = 0;
+  for (uint32_t i = 0; i < n; ++i) {
+    const auto& s = static_cast<const std::string_view*>(sv)[i];
+    lengths[i] = (uint32_t)s.size();
+    if (!s.empty()) memcpy(bytes + off, s.data(), s.size());
+    off += s.size();
+  }
+}
+int nblh_sizeof_string_view() { return (int)sizeof(std::string_view); }
+
+// ---- stripe decoder --------------------------------------------------------
+void* nblh_stripe_create(void* factory, const char* const* streams, const uint64_t* sizes, uint32_t n) {
+  StripeHandle* h = new StripeHandle();
+  const int rc = guard([&] {
+    std::vector<std::string_view> views;
+    for (uint32_t i = 0; i < n; ++i) h->streams.emplace_back(streams[i], sizes[i]);
+    for (auto& s : h->streams) views.emplace_back(s);
+    h->dec = std::make_unique<GpuStripeDecoder>(*static_cast<FactoryHandle*>(factory)->f, views);
+  });
+  if (rc != 0) {
+    delete h;
+    return nullptr;
+  }
+  return h;
+}
+void nblh_stripe_free(void* s) { delete static_cast<StripeHandle*>(s); }
+int nblh_stripe_next(void* s, uint32_t stream, uint32_t count, void* output, void* nulls, int* requested, const void* scatter,
+                     uint32_t scatter_size, uint32_t* non_null, uint32_t* n_string_buffers) {
+  return guard([&] {
+    int req = 0;
+    Bitmap bm{scatter, scatter_size};
+    std::vector<std::shared_ptr<void>> bufs;
+    std::function<void*()> getNulls;
+    if (nulls) getNulls = [&]() { req = 1; return nulls; };
+    *non_null = static_cast<StripeHandle*>(s)->dec->decoder(stream).next(count, output, bufs, getNulls, scatter ? &bm : nullptr);
+    if (requested) *requested = req;
+    if (n_string_buffers) *n_string_buffers = (uint32_t)bufs.size();
+  });
+}
+int nblh_stripe_skip(void* s, uint32_t stream, uint32_t count) {
+  return guard([&] { static_cast<StripeHandle*>(s)->dec->decoder(stream).skip(count); });
+}
+int nblh_stripe_reset(void* s, uint32_t stream) {
+  return guard([&] { static_cast<StripeHandle*>(s)->dec->decoder(stream).reset(); });
+}
+
+}  // extern "C"

@@ -1,0 +1,173 @@
+"""ctypes access to the C++ host layer (nimble_amd/host): GpuEncodingFactory,
+its Encoding objects and GpuStripeDecoder, with the same Python surface as
+oracle.oracle.Encoding / StreamDecoder so one contract test drives both."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from nimble_amd import build as nb
+from nimble_amd import wire as W
+
+_lib = None
+
+
+class HostError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        import torch  # noqa: F401  (loads the HIP runtime the libraries share)
+        from nimble_amd import capi
+
+        capi.lib()
+        if not os.path.exists(nb.HOST_LIB_PATH):
+            raise ImportError(f"{nb.HOST_LIB_PATH} missing: run __graft_entry__.build()")
+        L = C.CDLL(nb.HOST_LIB_PATH)
+        vp, u32, u64, i32 = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+        L.nblh_last_error.restype = C.c_char_p
+        L.nblh_factory_create.restype = vp
+        L.nblh_factory_create.argtypes = [i32, i32]
+        L.nblh_factory_free.argtypes = [vp]
+        L.nblh_encoding_create.restype = vp
+        L.nblh_encoding_create.argtypes = [vp, vp, u64]
+        L.nblh_encoding_free.argtypes = [vp]
+        for f in ("nblh_row_count", "nblh_null_count"):
+            getattr(L, f).restype = u32
+            getattr(L, f).argtypes = [vp]
+        for f in ("nblh_is_nullable", "nblh_data_type", "nblh_encoding_type", "nblh_reset"):
+            getattr(L, f).restype = i32
+            getattr(L, f).argtypes = [vp]
+        L.nblh_skip.argtypes = [vp, u32]
+        L.nblh_materialize.argtypes = [vp, u32, vp]
+        L.nblh_materialize_bools_as_bits.argtypes = [vp, u32, vp, i32]
+        L.nblh_materialize_nullable.argtypes = [vp, u32, vp, vp, C.POINTER(i32), vp, u32, u32, C.POINTER(u32)]
+        L.nblh_sv_total.restype = u64
+        L.nblh_sv_total.argtypes = [vp, u32]
+        L.nblh_sv_flatten.argtypes = [vp, u32, vp, vp]
+        L.nblh_stripe_create.restype = vp
+        L.nblh_stripe_create.argtypes = [vp, C.POINTER(C.c_char_p), vp, u32]
+        L.nblh_stripe_free.argtypes = [vp]
+        L.nblh_stripe_next.argtypes = [vp, u32, u32, vp, vp, C.POINTER(i32), vp, u32, C.POINTER(u32), C.POINTER(u32)]
+        L.nblh_stripe_skip.argtypes = [vp, u32, u32]
+        L.nblh_stripe_reset.argtypes = [vp, u32]
+        _lib = L
+    return _lib
+
+
+def _chk(rc):
+    if rc != 0:
+        raise HostError(lib().nblh_last_error().decode(errors="replace"))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Factory:
+    def __init__(self, varint_rows: bool = False, device: int = 0):
+        self._h = lib().nblh_factory_create(int(varint_rows), device)
+        if not self._h:
+            _chk(-1)
+
+    def create(self, data) -> "HostEncoding":
+        return HostEncoding(self, data)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().nblh_factory_free(self._h)
+            self._h = None
+
+
+class HostEncoding:
+    def __init__(self, factory: Factory, data):
+        self._data = np.frombuffer(bytes(data), dtype=np.uint8).copy()
+        self._factory = factory
+        self._h = lib().nblh_encoding_create(factory._h, _p(self._data), self._data.size)
+        if not self._h:
+            _chk(-1)
+        self.row_count = lib().nblh_row_count(self._h)
+        self.data_type = lib().nblh_data_type(self._h)
+        self.encoding_type = lib().nblh_encoding_type(self._h)
+        self.is_nullable = bool(lib().nblh_is_nullable(self._h))
+        self.null_count = lib().nblh_null_count(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().nblh_encoding_free(self._h)
+            self._h = None
+
+    def reset(self):
+        _chk(lib().nblh_reset(self._h))
+
+    def skip(self, n):
+        _chk(lib().nblh_skip(self._h, n))
+
+    def materialize(self, n):
+        if self.data_type == W.STRING:
+            sv = np.zeros(2 * n, dtype=np.uint64)
+            _chk(lib().nblh_materialize(self._h, n, _p(sv)))
+            total = lib().nblh_sv_total(_p(sv), n)
+            lengths = np.zeros(n, dtype=np.uint32)
+            blob = np.zeros(max(int(total), 1), dtype=np.uint8)
+            lib().nblh_sv_flatten(_p(sv), n, _p(lengths), _p(blob))
+            return lengths, blob[: int(total)]
+        dt = np.uint8 if self.data_type == W.BOOL else W.physical_dtype(self.data_type)
+        out = np.empty(n, dtype=dt)
+        _chk(lib().nblh_materialize(self._h, n, _p(out)))
+        return out
+
+    def materialize_bools_as_bits(self, n, buffer, begin):
+        _chk(lib().nblh_materialize_bools_as_bits(self._h, n, _p(buffer), begin))
+
+    def materialize_nullable(self, n, buffer, nulls, scatter=None, scatter_size=0, offset=0):
+        req = C.c_int(0)
+        nn = C.c_uint32(0)
+        _chk(lib().nblh_materialize_nullable(self._h, n, _p(buffer), _p(nulls), C.byref(req), _p(scatter), scatter_size,
+                                             offset, C.byref(nn)))
+        return nn.value, bool(req.value)
+
+
+class StripeDecoder:
+    """GpuStripeDecoder: all streams of a stripe decoded in one GPU batch."""
+
+    def __init__(self, factory: Factory, streams):
+        self._factory = factory
+        self._streams = [bytes(s) for s in streams]
+        arr = (C.c_char_p * len(self._streams))(*self._streams)
+        sizes = np.array([len(s) for s in self._streams], dtype=np.uint64)
+        self._h = lib().nblh_stripe_create(factory._h, arr, _p(sizes), len(self._streams))
+        if not self._h:
+            _chk(-1)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().nblh_stripe_free(self._h)
+            self._h = None
+
+    def stream(self, i):
+        return _StreamView(self, i)
+
+
+class _StreamView:
+    def __init__(self, stripe, idx):
+        self._s, self._i = stripe, idx
+
+    def reset(self):
+        _chk(lib().nblh_stripe_reset(self._s._h, self._i))
+
+    def skip(self, n):
+        _chk(lib().nblh_stripe_skip(self._s._h, self._i, n))
+
+    def next(self, count, output, nulls=None, scatter=None, scatter_size=0):
+        req = C.c_int(0)
+        nn = C.c_uint32(0)
+        nb_ = C.c_uint32(0)
+        _chk(lib().nblh_stripe_next(self._s._h, self._i, count, _p(output), _p(nulls), C.byref(req), _p(scatter),
+                                    scatter_size, C.byref(nn), C.byref(nb_)))
+        self.last_string_buffers = nb_.value
+        return nn.value, bool(req.value)

@@ -1,0 +1,197 @@
+"""GPU: the C++ host layer (GpuEncodingFactory -> Encoding, GpuStripeDecoder ->
+Decoder) honours the reference's Encoding / Decoder contracts, with the GPU
+doing the decode.  The same checks run against the CPU oracle in
+test_oracle_semantics.py (encodings/tests/EncodingTest.cpp:682-1021,
+velox/tests/ChunkedStreamDecoderTest.cpp:175-259)."""
+import numpy as np
+import pytest
+
+from nimble_amd import encoder as E
+from nimble_amd import wire as W
+
+from encoding_contract import check_materialize_patterns, check_nullable_scattered, check_scattered_materialize
+from util import patterns, phys, random_data, random_strings, rle_data
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def factory(gpu):
+    import host_shim
+
+    return host_shim.Factory()
+
+
+SPECS = {
+    "trivial": E.Trivial(), "fbw": E.FixedBitWidth(), "rle": E.RLE(), "dictionary": E.Dictionary(),
+    "mainly_constant": E.MainlyConstant(), "varint": E.Varint(),
+}
+
+
+@pytest.mark.parametrize("dtype", [W.INT8, W.UINT16, W.INT32, W.INT64, W.FLOAT, W.DOUBLE])
+def test_numeric_contract(factory, dtype):
+    rng = np.random.default_rng(500 + dtype)
+    for n in (1, 33, 700):
+        for pname, data in patterns(rng, dtype, n):
+            for sname, spec in SPECS.items():
+                if sname == "varint" and W.elem_bytes(dtype) < 4:
+                    continue
+                e = factory.create(E.encode(spec, data, dtype))
+                assert e.row_count == n and e.data_type == dtype
+                check_materialize_patterns(e, phys(data, dtype), dtype, rng)
+                e.reset()
+                check_scattered_materialize(e, phys(data, dtype), dtype, rng)
+
+
+def test_bool_contract(factory):
+    rng = np.random.default_rng(5)
+    for n in (1, 64, 65, 500):
+        for p in (0.05, 0.5):
+            b = rng.random(n) < p
+            for spec in (E.Trivial(), E.SparseBool(), E.RLE()):
+                e = factory.create(E.encode(spec, b, W.BOOL))
+                check_materialize_patterns(e, b.astype(np.uint8), W.BOOL, rng)
+                e.reset()
+                check_scattered_materialize(e, b.astype(np.uint8), W.BOOL, rng)
+                e.reset()
+                words = np.zeros((n + 70) // 64 + 2, dtype=np.uint64)
+                e.materialize_bools_as_bits(n // 2, words, 5)
+                e.materialize_bools_as_bits(n - n // 2, words, 5 + n // 2)
+                assert np.array_equal(np.unpackbits(words.view(np.uint8), bitorder="little")[5:5 + n].astype(bool), b)
+
+
+def test_string_contract(factory):
+    rng = np.random.default_rng(6)
+    for n in (1, 50, 400):
+        col = random_strings(rng, n)
+        alpha = random_strings(rng, 17)
+        picked = alpha.take(rng.integers(0, 17, n))
+        for spec, c in ((E.Trivial(), col), (E.Dictionary(), picked), (E.MainlyConstant(other=E.Trivial()), picked),
+                        (E.Constant(), alpha.take(np.zeros(n, dtype=np.int64)))):
+            e = factory.create(E.encode(spec, c, W.STRING))
+            check_materialize_patterns(e, (c.lengths, c.blob), W.STRING, rng)
+
+
+@pytest.mark.parametrize("dtype", [W.INT32, W.INT64, W.DOUBLE])
+def test_nullable_contract(factory, dtype):
+    rng = np.random.default_rng(77 + dtype)
+    for n in (1, 10, 333):
+        for p_null in (0.0, 0.2, 0.8, 1.0):
+            mask = rng.random(n) >= p_null
+            vals = rle_data(rng, dtype, int(mask.sum())) if mask.any() else random_data(rng, dtype, 0)
+            for spec in (E.Nullable(data=E.Trivial(), nulls=E.Trivial()), E.Nullable(data=E.FixedBitWidth(), nulls=E.SparseBool())):
+                e = factory.create(E.encode_nullable(spec, vals, mask, dtype))
+                assert e.is_nullable and e.null_count == n - int(mask.sum())
+                check_nullable_scattered(e, phys(vals, dtype), mask, rng)
+                e.reset()
+                want = np.zeros(n, dtype=W.physical_dtype(dtype))
+                want[mask] = phys(vals, dtype)
+                assert np.array_equal(e.materialize(n), want)
+
+
+def test_error_convention(factory):
+    import host_shim
+
+    ok = E.encode(E.Trivial(), np.arange(4, dtype=np.int32), W.INT32)
+    with pytest.raises(host_shim.HostError, match="Unexpected trivial encoding end"):
+        factory.create(ok + b"\x00")
+    with pytest.raises(host_shim.HostError, match="invalid EncodingType"):
+        factory.create(bytes([77]) + ok[1:])
+    with pytest.raises(host_shim.HostError, match="not decoded on the GPU"):
+        factory.create(bytes([8]) + ok[1:])  # Delta: the integration's fallback handles it
+    e = factory.create(ok)
+    with pytest.raises(host_shim.HostError, match="past the end"):
+        e.materialize(5)
+
+
+def _stream(rng, dtype, with_nulls, max_chunks=10, max_rows=10):
+    chunks, values, masks = [], [], []
+    for _ in range(int(rng.integers(1, max_chunks + 1))):
+        n = int(rng.integers(1, max_rows + 1))
+        nullable = with_nulls and bool(rng.integers(0, 2))
+        mask = (rng.random(n) < 0.6) if nullable else np.ones(n, dtype=bool)
+        v = random_data(rng, dtype, int(mask.sum()))
+        if nullable:
+            chunks.append(E.encode_nullable(E.Nullable(data=E.Trivial(), nulls=E.Trivial()), v, mask, dtype))
+        else:
+            chunks.append(E.encode(E.FixedBitWidth(), v, dtype))
+        full = np.zeros(n, dtype=W.physical_dtype(dtype))
+        full[mask] = phys(v, dtype)
+        values.append(full)
+        masks.append(mask)
+    return E.stream(chunks), np.concatenate(values), np.concatenate(masks)
+
+
+def test_stripe_decoder_matches_oracle_stream_decoder(factory, oracle):
+    """Many streams of one stripe decoded in ONE GPU batch; every stream then
+    read through Decoder::next in every batch size, dense and scattered."""
+    import host_shim
+
+    rng = np.random.default_rng(12)
+    made = [_stream(rng, dt, nulls) for dt in (W.INT32, W.INT64, W.DOUBLE, W.INT16) for nulls in (False, True) for _ in range(3)]
+    stripe = host_shim.StripeDecoder(factory, [m[0] for m in made])
+    for si, (stream, values, mask) in enumerate(made):
+        total = values.size
+        gd = stripe.stream(si)
+        od = oracle.StreamDecoder(stream)
+        for batch in sorted({1, 2, 3, max(1, total // 2), total}):
+            gd.reset()
+            od.reset()
+            pos = 0
+            while pos < total:
+                n = min(batch, total - pos)
+                gout = np.zeros(n, dtype=values.dtype)
+                oout = np.zeros(n, dtype=values.dtype)
+                gn = np.zeros((n + 7) // 8 + 8, dtype=np.uint8)
+                on = np.zeros((n + 7) // 8 + 8, dtype=np.uint8)
+                gnn, greq = gd.next(n, gout, gn)
+                onn, oreq = od.next(n, oout, on)
+                assert (gnn, greq) == (onn, oreq)
+                m = mask[pos:pos + n]
+                assert gnn == int(m.sum())
+                assert np.array_equal(gout[m], values[pos:pos + n][m])
+                if greq:
+                    assert np.array_equal(gn[:(n + 7) // 8], on[:(n + 7) // 8])
+                pos += n
+        # skip + scattered read
+        skip = int(rng.integers(0, total))
+        gd.reset()
+        gd.skip(skip)
+        n = total - skip
+        scatter = []
+        while sum(scatter) < n:
+            scatter.append(bool(rng.integers(0, 2)))
+        scatter = np.array(scatter, dtype=bool)
+        sbits = np.zeros((scatter.size + 7) // 8 + 8, dtype=np.uint8)
+        sbits[:(scatter.size + 7) // 8] = np.packbits(scatter.astype(np.uint8), bitorder="little")
+        out = np.zeros(scatter.size, dtype=values.dtype)
+        nulls = np.zeros((scatter.size + 7) // 8 + 8, dtype=np.uint8)
+        nn, req = gd.next(n, out, nulls, sbits, scatter.size)
+        m = mask[skip:]
+        slots = np.flatnonzero(scatter)[m]
+        assert nn == int(m.sum())
+        assert np.array_equal(out[slots], values[skip:][m])
+        if nn != scatter.size:
+            want = np.zeros(scatter.size, dtype=bool)
+            want[slots] = True
+            assert np.array_equal(np.unpackbits(nulls, bitorder="little")[:scatter.size].astype(bool), want)
+
+
+def test_stripe_decoder_strings(factory):
+    import host_shim
+
+    rng = np.random.default_rng(13)
+    cols = [random_strings(rng, int(rng.integers(1, 40))) for _ in range(4)]
+    stream = E.stream([E.encode(E.Trivial(), c, W.STRING) for c in cols])
+    stripe = host_shim.StripeDecoder(factory, [stream])
+    d = stripe.stream(0)
+    total = sum(len(c) for c in cols)
+    sv = np.zeros(2 * total, dtype=np.uint64)
+    nn, _ = d.next(total, sv)
+    assert nn == total and d.last_string_buffers >= 1
+    lengths = np.zeros(total, dtype=np.uint32)
+    n_bytes = host_shim.lib().nblh_sv_total(sv.ctypes.data, total)
+    blob = np.zeros(max(int(n_bytes), 1), dtype=np.uint8)
+    host_shim.lib().nblh_sv_flatten(sv.ctypes.data, total, lengths.ctypes.data, blob.ctypes.data)
+    assert np.array_equal(lengths, np.concatenate([c.lengths for c in cols]))
+    assert np.array_equal(blob[:int(n_bytes)], np.concatenate([c.blob for c in cols]))
