@@ -33,6 +33,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=10_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the H2D+decode+D2H measurement")
     ap.add_argument("--cpu-sample-chunks", type=int, default=0, help="0 = first chunk of every column")
     ap.add_argument("--check", action="store_true", help="verify a sample of the output against the oracle")
     return ap.parse_args()
@@ -69,6 +70,33 @@ def cpu_baseline(chunks, min_seconds=12.0):
     }
 
 
+def pcie_inclusive(dec, plan, torch, device, steps=5):
+    """The same step with the host at both ends: H2D of the encoded bytes from
+    pinned memory, decode, D2H of the decoded output into pinned memory.
+    Reported beside the headline value, never as it."""
+    enc = int(plan.buffer.size)
+    h_in = torch.empty(enc, dtype=torch.uint8).pin_memory()
+    h_in.numpy()[:] = plan.buffer
+    h_out = torch.empty(int(plan.info.out_bytes), dtype=torch.uint8).pin_memory()
+
+    def one():
+        dec.arena[:enc].copy_(h_in, non_blocking=True)
+        dec.decode()
+        h_out.copy_(dec.out, non_blocking=True)
+
+    one()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    decoded = int(plan.info.decoded_bytes)
+    return {"decoded_gbs": round(decoded / dt / 1e9, 2), "ms_per_step": round(dt * 1e3, 3), "h2d_bytes": enc,
+            "d2h_bytes": int(plan.info.out_bytes), "steps": steps,
+            "link_gbs": round((enc + int(plan.info.out_bytes)) / dt / 1e9, 2)}
+
+
 def main():
     args = parse_args()
     import torch
@@ -84,11 +112,14 @@ def main():
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
-    from nimble_amd import workloads
+    from nimble_amd import shard, workloads
     from nimble_amd.decoder import BatchDecoder, Plan
 
     t_gen = time.perf_counter()
-    chunks = workloads.fbw_rle_table(args.rows, seed=42 + rank)  # each rank owns one stripe
+    # one stripe of identical shape per GPU (weak scaling); ownership by the same
+    # assignment a file reader uses, computed on every rank without communication
+    stripe = shard.assign_stripes([args.rows] * n_gpus, n_gpus)[rank][0]
+    chunks = workloads.fbw_rle_table(args.rows, seed=42 + stripe)
     buf, offs = workloads.pack_chunks(chunks)
     t_gen = time.perf_counter() - t_gen
     plan = Plan(buf, offs)
@@ -97,33 +128,27 @@ def main():
     info = plan.info
     launches = plan.launches()
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(device)
-
     for _ in range(args.warmup):
         dec.decode()
     dec.status()  # also synchronises; raises if a kernel flagged bad data
 
-    # timed region: K steps, per-launch HIP events recorded on the decode stream
+    # timed region: exactly K steps between barrier + device synchronise on both
+    # sides, max over ranks; per-launch HIP events recorded on the decode stream
     dec.profile_begin(args.steps)
-    barrier()
-    t0 = time.perf_counter()
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
-    ev0.record()
-    for s in range(args.steps):
+
+    def step(s):
+        if s == 0:
+            ev0.record()
         dec.decode_profiled(s)
-    ev1.record()
-    barrier()
-    wall = time.perf_counter() - t0
+        if s == args.steps - 1:
+            ev1.record()
+
+    elapsed = shard.timed_steps(step, args.steps, lambda: torch.cuda.synchronize(device), dist if world > 1 else None)
     dev_ms = ev0.elapsed_time(ev1)
     launch_ms = dec.profile_end()
-    elapsed = torch.tensor([wall], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
-    elapsed = float(elapsed.item())
+    dec.status()
 
     decoded = int(info.decoded_bytes)
     rows = int(info.total_rows)
@@ -148,6 +173,17 @@ def main():
         "kernel": f"{dom_key[0]}<{dom_key[1]}>", "kernel_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
         "algorithmic_bytes_per_launch": dom["alg"] // max(dom["launches"], 1),
     }
+    # HBM bytes per launch from the PMC passes of this same command (FETCH_SIZE and
+    # WRITE_SIZE collected in separate rocprofv3 runs, corrected by tools/pmc_traffic.py)
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        pmc = json.load(open(path))
+        k = pmc.get("kernels", {}).get(roofline["kernel"])
+        if pmc.get("rows") == args.rows and k:
+            roofline["traffic"] = k["traffic_bytes"]
+            roofline["traffic_over_algorithmic"] = round(k["traffic_bytes"] / max(roofline["algorithmic_bytes_per_launch"], 1), 4)
+            roofline["traffic_source"] = os.path.relpath(path, ROOT)
+            break
     whole = (int(info.encoded_bytes) + decoded) / (sum(launch_ms) * 1e-3) / 1e9 if sum(launch_ms) > 0 else 0.0
 
     result = {
@@ -185,6 +221,8 @@ def main():
             assert_chunk_equal(slice_chunk(host, plan.layouts[i]), oracle_chunk(O, chunks[i][1]), chunks[i][0])
         result["checked_chunks"] = len(range(0, len(chunks), 7))
 
+    if rank == 0 and n_gpus == 1 and not args.no_pcie:
+        result["pcie_inclusive"] = pcie_inclusive(dec, plan, torch, device)
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(chunks)
     if rank == 0:
