@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Headline benchmark: device-resident decode of the "10M-row int32/int64
-columns, fixed-bit-width + RLE cascades" table (BASELINE.json configs[1]).
+columns, fixed-bit-width + RLE cascades" table.
 
 One step = one pass of the decode path over the whole batch (every chunk of every
 column of a 10M-row stripe), inputs and descriptor tables already resident in

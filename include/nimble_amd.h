@@ -14,7 +14,7 @@
  *
  * The reference has no FFI; a maintainer binds these entry points from a
  * subclass of nimble::EncodingFactory / an implementation of nimble::Decoder
- * (dwio/nimble/velox/Decoder.h:27-56), see INTEGRATION.md.
+ * (dwio/nimble/velox/Decoder.h:27-56); nimble_amd/host/ holds both classes.
  *
  * Conventions: plain pointers and sizes only; every function returns an
  * nbl_status (0 = ok); nbl_last_error() gives the message of the calling

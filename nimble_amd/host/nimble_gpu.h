@@ -10,8 +10,8 @@
 // Velox is not available to this build, so the two Velox types in those
 // signatures are replaced by the smallest equivalents: the MemoryPool argument
 // is dropped (host memory comes from the C++ allocator) and bits::Bitmap is the
-// two-field view below.  INTEGRATION.md shows the adapter a Nimble maintainer
-// adds to plug these classes into the real interfaces.
+// two-field view below.  A Nimble maintainer plugs these classes into the real
+// interfaces with a thin adapter that forwards each virtual one-to-one.
 #pragma once
 
 #include <cstdint>

@@ -46,7 +46,7 @@ def run_length_values(rng, n: int, lo: int = 10, hi: int = 60, card: int = 1000,
 
 
 def fbw_rle_table(rows: int = 10_000_000, seed: int = 42):
-    """BASELINE config "10M-row int32/int64 columns, fixed-bit-width + RLE cascades"."""
+    """Benchmark table "10M-row int32/int64 columns, fixed-bit-width + RLE cascades"."""
     rng = np.random.default_rng(seed)
     chunks = []
     for dtype, widths, npt in ((W.INT32, FBW_WIDTHS_32, np.uint32), (W.INT64, FBW_WIDTHS_64, np.uint64)):
@@ -71,7 +71,7 @@ def fbw_rle_table(rows: int = 10_000_000, seed: int = 42):
 
 
 def cpu_reference_column(rows: int = 1_000_000, seed: int = 42):
-    """BASELINE config "1M-row int64 column (bit-packed + RLE)": one chunk, byte-rounded and exact widths."""
+    """Benchmark column "1M-row int64 column (bit-packed + RLE)": one chunk, byte-rounded and exact widths."""
     rng = np.random.default_rng(seed)
     vals = run_length_values(rng, rows).astype(np.uint64)
     out = []
