@@ -31,7 +31,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=10_000_000)
+    ap.add_argument("--rows", type=int, default=0, help="rows per column (default: the workload's own size)")
+    ap.add_argument("--workload", default="fbw_rle", choices=["fbw_rle", "dict_string", "mixed", "wide"],
+                    help="fbw_rle is the headline configuration; the others are the remaining benchmark tables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the H2D+decode+D2H measurement")
     ap.add_argument("--cpu-sample-chunks", type=int, default=0, help="0 = first chunk of every column")
@@ -47,7 +49,8 @@ def cpu_baseline(chunks, min_seconds=12.0):
 
     lib = O.lib()
     arrays = [np.frombuffer(enc, dtype=np.uint8) for _, enc in chunks]
-    meta = [(int(np.frombuffer(enc[2:6], dtype=np.uint32)[0]), {5: 4, 6: 4, 7: 8, 8: 8}[enc[1]]) for _, enc in chunks]
+    es_of = {1: 1, 2: 1, 3: 2, 4: 2, 5: 4, 6: 4, 7: 8, 8: 8, 9: 4, 10: 8, 11: 1, 12: 16}
+    meta = [(int(np.frombuffer(enc[2:6], dtype=np.uint32)[0]), es_of[enc[1]]) for _, enc in chunks]
     vals = np.zeros(max(n * es for n, es in meta) + 64, dtype=np.uint8)
     out_bytes = rows = passes = 0
     t0 = time.perf_counter()
@@ -119,7 +122,9 @@ def main():
     # one stripe of identical shape per GPU (weak scaling); ownership by the same
     # assignment a file reader uses, computed on every rank without communication
     stripe = shard.assign_stripes([args.rows] * n_gpus, n_gpus)[rank][0]
-    chunks = workloads.fbw_rle_table(args.rows, seed=42 + stripe)
+    default_rows = {"fbw_rle": 10_000_000, "dict_string": 10_000_000, "mixed": 1_250_000, "wide": 100_000}
+    args.rows = args.rows or default_rows[args.workload]
+    chunks = workloads.WORKLOADS[args.workload](args.rows, 42 + stripe)
     buf, offs = workloads.pack_chunks(chunks)
     t_gen = time.perf_counter() - t_gen
     plan = Plan(buf, offs)
@@ -179,7 +184,7 @@ def main():
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         pmc = json.load(open(path))
         k = pmc.get("kernels", {}).get(roofline["kernel"])
-        if pmc.get("rows") == args.rows and k:
+        if pmc.get("rows") == args.rows and pmc.get("workload", "fbw_rle") == args.workload and k:
             roofline["traffic"] = k["traffic_bytes"]
             roofline["traffic_over_algorithmic"] = round(k["traffic_bytes"] / max(roofline["algorithmic_bytes_per_launch"], 1), 4)
             roofline["traffic_source"] = os.path.relpath(path, ROOT)
@@ -192,9 +197,14 @@ def main():
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {
-            "workload": f"{args.rows // 1_000_000}M-row int32/int64 columns, fixed-bit-width + RLE cascades "
-                        f"(8 int32 + 16 int64 FBW widths, 4 RLE columns; <=20MiB raw chunks; one stripe per GPU)",
-            "rows_per_gpu": args.rows, "columns": 28, "chunks_per_gpu": int(info.n_chunks),
+            "workload": {
+                "fbw_rle": f"{args.rows // 1_000_000}M-row int32/int64 columns, fixed-bit-width + RLE cascades "
+                           f"(8 int32 + 16 int64 FBW widths, 4 RLE columns; <=20MiB raw chunks; one stripe per GPU)",
+                "dict_string": f"{args.rows}-row dictionary-encoded string columns (3 alphabet sizes) with nullable wrapper",
+                "mixed": f"mixed-type 100-column table, 3-level cascades, one {args.rows}-row stripe per GPU",
+                "wide": f"wide ML table, 5000 sparse/nullable float columns, one {args.rows}-row stripe per GPU",
+            }[args.workload],
+            "rows_per_gpu": args.rows, "chunks_per_gpu": int(info.n_chunks), "nodes_per_gpu": int(info.n_nodes),
             "launches_per_step": int(info.n_launches), "parallelism": f"stripe-sharded x{n_gpus}",
         },
         "rows_per_s": round(rows * n_gpus * args.steps / elapsed),

@@ -34,7 +34,8 @@ from . import wire as W
 __all__ = [
     "StringColumn", "Trivial", "FixedBitWidth", "Varint", "Constant", "RLE",
     "Dictionary", "Nullable", "SparseBool", "MainlyConstant", "encode",
-    "encode_nullable", "chunk", "stream", "bitpack", "varint_bytes",
+    "encode_nullable", "encode_dictionary_from_indices", "nullable_wrap", "mainly_constant_from_parts",
+    "chunk", "stream", "bitpack", "varint_bytes",
     "bits_required",
 ]
 
@@ -232,15 +233,6 @@ def _bitmap(bools: np.ndarray) -> bytes:
     return np.packbits(b, bitorder="little").tobytes() + bytes(W.FBA_SLOP)
 
 
-def _value_bytes(value, dtype: int) -> bytes:
-    if dtype == W.STRING:
-        return struct.pack("<I", len(value)) + bytes(value)
-    if dtype == W.BOOL:
-        return bytes([1 if value else 0])
-    return np.array([value]).astype(W.physical_dtype(dtype), copy=False).tobytes() if not isinstance(
-        value, np.generic) else np.array([value]).view(W.physical_dtype(dtype)).tobytes()
-
-
 # --------------------------------------------------------------------------
 # encoders
 # --------------------------------------------------------------------------
@@ -388,6 +380,50 @@ def encode_nullable(spec: Nullable, non_null_values: Values, non_null_mask: np.n
     data = encode(spec.data, non_null_values, dtype, varint_rows)
     nulls = encode(spec.nulls, mask, W.BOOL, varint_rows)
     return prefix(W.NULLABLE, dtype, n, varint_rows) + struct.pack("<I", len(data)) + data + nulls
+
+
+def encode_dictionary_from_indices(spec: Dictionary, alphabet: Values, indices: np.ndarray, dtype: int,
+                                    varint_rows: bool = False) -> bytes:
+    """Dictionary encoding of `alphabet[indices]` without materialising the rows
+    (for multi-million-row string columns).  `alphabet` must hold distinct
+    values; entries are re-ordered to first-occurrence order and unused ones
+    dropped, as the reference writer would (DictionaryEncoding.h:432-456)."""
+    indices = np.ascontiguousarray(indices, dtype=np.int64)
+    n = int(indices.size)
+    used, first_idx, inverse = np.unique(indices, return_index=True, return_inverse=True)
+    order = np.argsort(first_idx, kind="stable")
+    rank = np.empty_like(order)
+    rank[order] = np.arange(order.size)
+    new_indices = rank[inverse].astype(np.uint32)
+    picked = used[order]
+    alpha_vals = alphabet.take(picked) if dtype == W.STRING else _phys(alphabet, dtype)[picked]
+    alpha = encode(spec.alphabet, alpha_vals, dtype, varint_rows)
+    return (prefix(W.DICTIONARY, dtype, n, varint_rows) + struct.pack("<I", len(alpha)) + alpha +
+            encode(spec.indices, new_indices, W.UINT32, varint_rows))
+
+
+def mainly_constant_from_parts(spec: MainlyConstant, is_common: np.ndarray, other: np.ndarray, common, dtype: int,
+                               varint_rows: bool = False) -> bytes:
+    """MainlyConstant assembled from its parts (no frequency count): row i is
+    `common` where is_common[i], else the next value of `other`
+    (MainlyConstantEncoding.h:69-75)."""
+    assert W.is_numeric(dtype)
+    is_common = np.ascontiguousarray(is_common).astype(np.bool_, copy=False)
+    other = _phys(np.ascontiguousarray(other), dtype)
+    assert int((~is_common).sum()) == other.size
+    ic = encode(spec.is_common, is_common, W.BOOL, varint_rows)
+    ov = encode(spec.other, other, dtype, varint_rows)
+    cv = _phys(np.array([common]), dtype).tobytes() if isinstance(common, np.generic) else \
+        np.array([common], dtype=W.physical_dtype(dtype)).tobytes()
+    return (prefix(W.MAINLY_CONSTANT, dtype, int(is_common.size), varint_rows) + struct.pack("<I", len(ic)) + ic +
+            struct.pack("<I", len(ov)) + ov + cv)
+
+
+def nullable_wrap(data_encoding: bytes, non_null_mask: np.ndarray, nulls_spec, dtype: int, varint_rows: bool = False) -> bytes:
+    """Nullable around an already-encoded non-null child (NullableEncoding.h:370-405)."""
+    mask = np.ascontiguousarray(non_null_mask).astype(np.bool_, copy=False)
+    nulls = encode(nulls_spec, mask, W.BOOL, varint_rows)
+    return prefix(W.NULLABLE, dtype, int(mask.size), varint_rows) + struct.pack("<I", len(data_encoding)) + data_encoding + nulls
 
 
 def _string_ids(col: StringColumn) -> np.ndarray:

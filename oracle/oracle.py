@@ -171,7 +171,19 @@ def decode_chunk(data, varint_rows: bool = False):
     if e.is_nullable:
         e.reset()
         if e.data_type == DT_STRING:
-            raise NotImplementedError
+            # the non-null bitmap is the second child (to the end of the chunk): decode it on its own
+            raw = bytes(data)
+            pre = 6
+            if varint_rows:
+                pre = 2
+                while raw[pre] & 0x80:
+                    pre += 1
+                pre += 1
+            size = int.from_bytes(raw[pre:pre + 4], "little")
+            ne = Encoding(raw[pre + 4 + size:], varint_rows)
+            bits = ne.materialize(ne.row_count)
+            return dict(values=vals, nulls=np.packbits(bits.astype(np.uint8), bitorder="little"),
+                        non_null=int(bits.sum()), rows=n, data_type=e.data_type)
         buf = np.zeros(n, dtype=vals.dtype)
         bm = np.zeros((n + 7) // 8 + 8, dtype=np.uint8)
         nn, req = e.materialize_nullable(n, buf, bm)
