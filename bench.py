@@ -36,6 +36,7 @@ def parse_args():
                     help="fbw_rle is the headline configuration; the others are the remaining benchmark tables")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the H2D+decode+D2H measurement")
+    ap.add_argument("--no-breakdown", action="store_true", help="skip the per-operation profile of the unfused plan")
     ap.add_argument("--cpu-sample-chunks", type=int, default=0, help="0 = first chunk of every column")
     ap.add_argument("--check", action="store_true", help="verify a sample of the output against the oracle")
     return ap.parse_args()
@@ -162,20 +163,31 @@ def main():
     value = total_decoded * args.steps / elapsed / 1e9
 
     # roofline of the dominant kernel (largest share of device time)
-    by_kernel = {}
-    for (name, es, nt, lvl, alg), ms in zip(launches, launch_ms):
-        k = by_kernel.setdefault((name, es), {"ms": 0.0, "alg": 0, "tiles": 0, "launches": 0})
-        k["ms"] += ms
-        k["alg"] += alg
-        k["tiles"] += nt
-        k["launches"] += 1
+    def group(launch_list, ms_list):
+        by = {}
+        for (name, es, nt, lvl, alg), ms in zip(launch_list, ms_list):
+            k = by.setdefault(name, {"ms": 0.0, "alg": 0, "tiles": 0, "launches": 0})
+            k["ms"] += ms
+            k["alg"] += alg
+            k["tiles"] += nt
+            k["launches"] += 1
+        return by
+
+    def table(by):
+        return [
+            {"kernel": k, "ms_per_step": round(v["ms"], 4), "launches": v["launches"], "tiles": v["tiles"],
+             "algorithmic_gbs": round(v["alg"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 and v["alg"] else None}
+            for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])
+        ]
+
+    by_kernel = group(launches, launch_ms)
     dom_key = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
     dom = by_kernel[dom_key]
     achieved = dom["alg"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] > 0 else 0.0
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-        "kernel": f"{dom_key[0]}<{dom_key[1]}>", "kernel_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
+        "kernel": dom_key, "kernel_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
         "algorithmic_bytes_per_launch": dom["alg"] // max(dom["launches"], 1),
     }
     # HBM bytes per launch from the PMC passes of this same command (FETCH_SIZE and
@@ -213,13 +225,27 @@ def main():
         "whole_batch_algorithmic_gbs": round(whole, 1),
         "whole_batch_hbm_frac": round(whole / HBM_PEAK_GBS, 4),
         "roofline": roofline,
-        "kernels": [
-            {"kernel": f"{k[0]}<{k[1]}>", "ms_per_step": round(v["ms"], 4), "launches": v["launches"], "tiles": v["tiles"],
-             "algorithmic_gbs": round(v["alg"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 and v["alg"] else None}
-            for k, v in sorted(by_kernel.items(), key=lambda kv: -kv[1]["ms"])
-        ],
+        "kernels": table(by_kernel),
         "gen_seconds": round(t_gen, 1),
     }
+
+    if rank == 0 and n_gpus == 1 and not args.no_breakdown:
+        # diagnostic, outside the timed region: the same batch with one launch per
+        # (level, operation), which attributes device time to operations
+        plan2 = Plan(buf, offs, per_kernel=True)
+        dec2 = BatchDecoder(plan2, str(device))
+        dec2.stage()
+        for _ in range(2):
+            dec2.decode()
+        dec2.status()
+        dec2.profile_begin(5)
+        for s in range(5):
+            dec2.decode_profiled(s)
+        ms2 = dec2.profile_end()
+        result["per_operation"] = {"launches_per_step": int(plan2.info.n_launches), "sum_ms_per_step": round(sum(ms2), 4),
+                                   "kernels": table(group(plan2.launches(), ms2))}
+        del dec2
+        plan2.close()
 
     if args.check and rank == 0:
         from oracle import oracle as O

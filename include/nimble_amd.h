@@ -53,7 +53,13 @@ enum {
 typedef struct nbl_options {
   uint32_t struct_size;            /* sizeof(nbl_options) */
   uint32_t use_varint_row_count;   /* Encoding::Options::useVarintRowCount */
+  uint32_t flags;                  /* NBL_PLAN_* (no counterpart in the reference) */
 } nbl_options;
+
+/* By default every cascade level of the batch is ONE kernel launch whose tiles
+ * name their own operation.  With this flag each (level, operation) pair is a
+ * launch of its own, so that a profiler attributes time to operations. */
+#define NBL_PLAN_PER_KERNEL_LAUNCHES 1u
 
 typedef struct nbl_plan nbl_plan;
 
@@ -140,7 +146,8 @@ nbl_status nbl_plan_upload(nbl_plan* plan, void* d_work, void* stream);
  * synchronisation.  Replaces Encoding::materialize / materializeNullable of
  * every chunk.  `d_arena` holds the encoded image (info.arena_bytes readable),
  * `d_out` receives the outputs (info.out_bytes), `d_work` is scratch
- * (info.work_bytes) already initialised by nbl_plan_upload.
+ * (info.work_bytes) already initialised by nbl_plan_upload.  The three device
+ * pointers must be 16-byte aligned (hipMalloc gives 256).
  */
 nbl_status nbl_decode_batch_device(const nbl_plan* plan, const void* d_arena,
                                    void* d_out, void* d_work, void* stream);
@@ -152,7 +159,8 @@ nbl_status nbl_decode_status(const nbl_plan* plan, const void* d_work, void* str
 
 /* One kernel launch of the plan (for profiling and roofline accounting). */
 typedef struct nbl_launch_info {
-  const char* kernel;      /* kernel family name, e.g. "k_materialize" */
+  const char* kernel;      /* kernel as a profiler names it, e.g. "k_materialize_fbw<8>",
+                            * "k_level<true>" (the fused launch of the last level) */
   uint32_t elem_bytes;     /* element-size specialisation (0 when not specialised) */
   uint32_t n_tiles;        /* workgroups */
   uint32_t level;          /* cascade step the launch belongs to */

@@ -29,7 +29,10 @@ EXPORTED_SYMBOLS = (
 
 
 class NblOptions(C.Structure):
-    _fields_ = [("struct_size", C.c_uint32), ("use_varint_row_count", C.c_uint32)]
+    _fields_ = [("struct_size", C.c_uint32), ("use_varint_row_count", C.c_uint32), ("flags", C.c_uint32)]
+
+
+PLAN_PER_KERNEL_LAUNCHES = 1
 
 
 class NblPlanInfo(C.Structure):

@@ -56,8 +56,26 @@ enum KernelId : uint32_t {
   K_SELECT_BITS,       // Nullable<bool>: scatter a bitmap by a bitmap
   K_MATERIALIZE_FBW,   // root FixedBitWidth, window-per-vector fast path
   K_MATERIALIZE_RAW,   // root Trivial / byte-aligned FixedBitWidth: copy (+ baseline)
-  K_COUNT
+  K_COUNT,
+  // Launch ids of the fused launches: one launch runs every step of a cascade
+  // level, each tile naming its own operation (TileRef::tile, high byte).
+  K_LEVEL = K_COUNT,   // any level but the last
+  K_LEVEL_LAST,        // the last level (the one that writes most of the output)
+  K_LAUNCH_COUNT
 };
+
+// Operation of a tile = kernel family + element size, packed into the high
+// byte of TileRef::tile; the low 24 bits are the tile number within the node.
+constexpr uint32_t kOpShift = 24;
+constexpr uint32_t kTileMask = (1u << kOpShift) - 1u;
+constexpr uint32_t es_slot(uint32_t es) { return es == 8 ? 3u : es == 4 ? 2u : es == 2 ? 1u : 0u; }
+constexpr uint32_t make_op(uint32_t kernel, uint32_t es) { return kernel * 4u + es_slot(es); }
+// Kernel families whose code depends on the element size; the others always use slot 0.
+constexpr bool kernel_has_es(uint32_t k) {
+  return k == K_MATERIALIZE || k == K_MATERIALIZE_FBW || k == K_MATERIALIZE_RAW || k == K_RLE_EXPAND ||
+         k == K_SELECT_SCATTER || k == K_DICT_GATHER || k == K_VARINT_DECODE;
+}
+constexpr uint32_t op_of(uint32_t kernel, uint32_t es) { return make_op(kernel, kernel_has_es(kernel) ? es : 1u); }
 
 enum NodeFlags : uint32_t {
   NF_INVERT_SEL = 1u << 0,   // select where the bit is 0 (MainlyConstant isCommon)
@@ -95,7 +113,7 @@ struct NodeDesc {
 
 struct TileRef {
   uint32_t node;   // index into the node table
-  uint32_t tile;   // tile number within that node for this kernel
+  uint32_t tile;   // make_op(kernel, es) << kOpShift | tile number within that node
 };
 
 // Addresses handed to every kernel.

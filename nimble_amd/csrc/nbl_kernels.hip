@@ -194,6 +194,34 @@ union Vec16 {
   u32x4 q;
   typename ElemT<ES>::type v[16 / ES];
 };
+// x.v[j] += base for every element (modular in the element width); the
+// narrow types add all the elements of a dword at once.
+template <int ES>
+__device__ __forceinline__ void vec_add_base(Vec16<ES>& x, typename ElemT<ES>::type base) {
+  if constexpr (ES >= 4) {
+#pragma unroll
+    for (uint32_t j = 0; j < 16 / ES; ++j) x.v[j] += base;
+  } else {
+    constexpr uint32_t H = ES == 2 ? 0x80008000u : 0x80808080u;  // top bit of each element
+    const uint32_t b = ES == 2 ? (uint32_t)base * 0x00010001u : (uint32_t)base * 0x01010101u;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+      const uint32_t v = x.q[k];
+      x.q[k] = ((v & ~H) + (b & ~H)) ^ ((v ^ b) & H);
+    }
+  }
+}
+// x.v[j] = val for a compile-time j on a zero-initialised vector; narrow
+// elements are shifted into their dword so the vector stays in registers.
+template <int ES>
+__device__ __forceinline__ void vec_set(Vec16<ES>& x, uint32_t j, typename ElemT<ES>::type val) {
+  if constexpr (ES >= 4) {
+    x.v[j] = val;
+  } else {
+    constexpr uint32_t per = 4 / ES;
+    x.q[j / per] |= (uint32_t)val << (8 * ES * (j % per));
+  }
+}
 
 // Store up to 16/ES elements starting at element e0 of `dst`; full vectors as
 // one 16-byte store.
@@ -215,37 +243,222 @@ __device__ __forceinline__ uint8_t* self_ptr(const NodeDesc& nd, const KArgs& a)
   return (nd.self.kind == COL_MAT_OUT ? a.out : a.work) + nd.self.off;
 }
 
+// ------------------------------------------------------------ column readers
+// A Reader fixes, at compile time, HOW a numeric column is read, so that the
+// loops using it are straight-line code: all loads of a tile are issued back
+// to back and their latencies overlap.  with_reader() picks the reader once
+// per tile from the (wave uniform) column descriptor.
+template <int CES>
+using elem_t = typename ElemT<CES>::type;
+
+template <int CES>
+__device__ __forceinline__ elem_t<CES> ld_elem(const uint8_t* p) {
+  elem_t<CES> v;
+  __builtin_memcpy(&v, p, CES);  // byte-unaligned global load
+  return v;
+}
+
+enum ReaderKind : int {
+  RK_PTR,    // CES-byte elements at any alignment (arena / work / out), + base
+  RK_FBW32,  // bit width <= 25: one unaligned dword covers a value
+  RK_FBW64,  // bit width <= 57: one unaligned qword covers a value
+  RK_FBW72,  // bit width 58..63 (8-byte elements only): qword + ninth byte
+  RK_CONST,  // every element == base
+};
+
+template <int RK, int CES>
+struct Reader {
+  using T = elem_t<CES>;
+  const uint8_t* p;
+  T base;
+  uint32_t w;
+  uint64_t mask;
+  __device__ __forceinline__ Reader(const ColRef& c, const KArgs& a) {
+    p = (c.kind == COL_MAT_WORK ? a.work : c.kind == COL_MAT_OUT ? (const uint8_t*)a.out : a.arena) + c.off;
+    base = (c.kind == COL_FBW || c.kind == COL_CONST) ? (T)c.base : (T)0;
+    w = c.width;
+    mask = wmask(w);
+  }
+  // value whose first bit is `sh` (0..7) bits into the byte at q
+  __device__ __forceinline__ T unpack(const uint8_t* q, uint32_t sh) const {
+    if constexpr (RK == RK_FBW32) {
+      return (T)((T)((ldu32(q) >> sh) & (uint32_t)mask) + base);
+    } else if constexpr (RK == RK_FBW64) {
+      return (T)((T)((ldu64(q) >> sh) & mask) + base);
+    } else {
+      uint64_t v = ldu64(q) >> sh;
+      v |= ((uint64_t)q[8] << 1) << (63u - sh);  // sh == 0 contributes nothing
+      return (T)((v & mask) + base);
+    }
+  }
+  // element i, any i < rows
+  __device__ __forceinline__ T get(uint64_t i) const {
+    if constexpr (RK == RK_PTR) {
+      return (T)(ld_elem<CES>(p + i * CES) + base);
+    } else if constexpr (RK == RK_CONST) {
+      return base;
+    } else {
+      const uint64_t bit = i * w;
+      return unpack(p + (bit >> 3), (uint32_t)bit & 7u);
+    }
+  }
+  // A view positioned at element `first` (wave uniform): at(rel) = element
+  // first + rel with 32-bit per-lane arithmetic on top of a scalar base.
+  // rel must stay below 2^24 (rel * 64 bits fits 32 bits).
+  struct View {
+    const Reader& r;
+    const uint8_t* q0;
+    uint32_t sh0;
+    __device__ __forceinline__ T at(uint32_t rel) const {
+      if constexpr (RK == RK_PTR) {
+        return (T)(ld_elem<CES>(q0 + rel * (uint32_t)CES) + r.base);
+      } else if constexpr (RK == RK_CONST) {
+        return r.base;
+      } else {
+        const uint32_t lb = sh0 + rel * r.w;
+        return r.unpack(q0 + (lb >> 3), lb & 7u);
+      }
+    }
+  };
+  __device__ __forceinline__ View view(uint64_t first) const {
+    if constexpr (RK == RK_PTR || RK == RK_CONST) {
+      return View{*this, p + first * CES, 0u};
+    } else {
+      const uint64_t bit = first * w;
+      return View{*this, p + (bit >> 3), (uint32_t)bit & 7u};
+    }
+  }
+};
+
+template <int CES, typename F>
+__device__ __forceinline__ void with_reader(const ColRef& c, const KArgs& a, F&& f) {
+  if (c.kind == COL_FBW && c.width != 8 * CES) {
+    if (c.width <= 25) {
+      f(Reader<RK_FBW32, CES>(c, a));
+    } else if (CES < 8 || c.width <= 57) {
+      f(Reader<RK_FBW64, CES>(c, a));
+    } else {
+      if constexpr (CES == 8) f(Reader<RK_FBW72, CES>(c, a));
+    }
+  } else if (c.kind == COL_CONST) {
+    f(Reader<RK_CONST, CES>(c, a));
+  } else {
+    f(Reader<RK_PTR, CES>(c, a));  // RAW, MAT_WORK, MAT_OUT, FBW at full width
+  }
+}
+
+// Iterations of a tile's four store rounds whose loads are kept in flight
+// together: eight element loads per thread (sixteen for 1-byte elements), a
+// register budget that keeps every body at eight waves per SIMD.
+template <int ES>
+constexpr uint32_t kBatch = ES == 8 ? 4 : ES == 4 ? 2 : 1;
+
+// LDS of one workgroup, shared by every body (the fused launch runs them all).
+constexpr uint32_t kSmemBytes = kTileBytes + 2048 + 1024 + 64;
+
+// =========================================================== tile bodies
+// Every body processes ONE tile of one node.  They are instantiated twice: in
+// a named __global__ wrapper (one kernel per operation) and in the fused
+// per-level kernel at the end of this file.
+
 // ------------------------------------------------------------- K_MATERIALIZE
 // Root leaf: FixedBitWidth unpack (+baseline), Trivial copy or Constant fill
-// straight into the output.  FixedBitWidthEncoding::materialize
+// straight into its destination.  FixedBitWidthEncoding::materialize
 // (encodings/FixedBitWidthEncoding.h:187-192), TrivialEncoding::materialize
 // (encodings/TrivialEncoding.h:295-300), ConstantEncoding (ConstantEncoding.h:72-77).
 //
-// Three launch variants keep each inner loop branch free:
-//   k_materialize_fbw : bit widths whose 16-byte output vector (V = 16/ES values)
-//                       is covered by one 16-byte window of packed bits
-//   k_materialize_raw : byte-aligned elements (Trivial, or bit width == 8*ES),
-//                       copy + baseline
-//   k_materialize     : everything else (Constant fill, odd width/type pairs)
+// Three variants keep each inner loop branch free:
+//   materialize_fbw : bit widths whose 16-byte output vector (V = 16/ES values)
+//                     is covered by one 16-byte window of packed bits
+//   materialize_raw : byte-aligned elements (Trivial, or bit width == 8*ES),
+//                     copy + baseline
+//   materialize     : everything else (Constant fill, odd width/type pairs)
 
-// Widths the window kernel handles (the planner uses the same predicate).
+// Widths the window variant handles (the planner uses the same predicate):
+// the V = 16/ES values of one output vector, plus up to 31 bits of shift, must
+// fit the five dwords a lane reads.
 __host__ __device__ constexpr bool fbw_window_ok(uint32_t es, uint32_t w) {
-  // V*w + (first-bit offset within its byte) must fit 128 bits; the offset is
-  // (e0*w)&7 with e0 a multiple of V, so it is 0 for ES<=2, {0,4} for ES=4 and
-  // {0,2,4,6} for ES=8.
-  // Width 63 (ES=8) overruns the window by up to 4 bits: the kernel then reads a fifth dword.
   return w >= 1 && (es == 8 ? w <= 63 : es == 4 ? w <= 31 : es == 2 ? w <= 15 : w <= 7);
 }
 
+// Byte-misaligned 16-byte global loads are served at about half the rate of
+// aligned ones once neighbouring lanes are more than two bytes apart, so wide
+// rows are not read with one misaligned window per lane.  Instead the
+// workgroup copies the tile's packed bytes into LDS with aligned, fully
+// coalesced 16-byte loads (every byte fetched once) and each lane assembles
+// its window from five dword-aligned LDS reads.
+//
+// stage_tile: copies [p - mis, p + nbytes + 4) to `stage` (mis = p & 15) and
+// returns mis; the caller synchronises.  ROUNDS * 4096 bytes must cover it.
+template <int ROUNDS>
+__device__ __forceinline__ uint32_t stage_tile(const uint8_t* p, uint32_t nbytes, u32x4* stage) {
+  const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 15u);
+  const u32x4* asrc = reinterpret_cast<const u32x4*>(p - mis);
+  const uint32_t nvec = (mis + nbytes + 4u + 15u) >> 4;  // + 4: the fifth dword of the last window
+  u32x4 g[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const uint32_t i = r * kBlock + threadIdx.x;
+    g[r] = asrc[i < nvec ? i : nvec - 1];
+  }
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const uint32_t i = r * kBlock + threadIdx.x;
+    if (i < nvec) stage[i] = g[r];
+  }
+  return mis;
+}
+// 128 bits starting `lb` bits into the staged bytes
+__device__ __forceinline__ void lds_window(const uint32_t* s32, uint32_t lb, uint32_t& n0, uint32_t& n1, uint32_t& n2, uint32_t& n3) {
+  const uint32_t d0 = lb >> 5, S = lb & 31u;
+  const uint32_t a = s32[d0], b = s32[d0 + 1], c = s32[d0 + 2], d = s32[d0 + 3], e = s32[d0 + 4];
+  n0 = __builtin_amdgcn_alignbit(b, a, S);
+  n1 = __builtin_amdgcn_alignbit(c, b, S);
+  n2 = __builtin_amdgcn_alignbit(d, c, S);
+  n3 = __builtin_amdgcn_alignbit(e, d, S);
+}
+
+// V values of w bits from the 128-bit window n0..n3 (w < 8*ES), + base
 template <int ES>
-__global__ __launch_bounds__(256) void k_materialize_fbw(KArgs a) {
+__device__ __forceinline__ void unpack_window(uint32_t n0, uint32_t n1, uint32_t n2, uint32_t n3, uint32_t w,
+                                              typename ElemT<ES>::type base, Vec16<ES>& x) {
+  using T = typename ElemT<ES>::type;
+  constexpr uint32_t V = 16 / ES;
+  const uint32_t mask32 = w >= 32 ? 0xFFFFFFFFu : ((1u << w) - 1u);
+  if constexpr (ES == 8) {
+    if (w < 32) {
+      const uint32_t v0 = n0 & mask32;
+      n0 = __builtin_amdgcn_alignbit(n1, n0, w);
+      x.v[0] = (uint64_t)v0 + base;
+      x.v[1] = (uint64_t)(n0 & mask32) + base;
+    } else {
+      const uint32_t wh = w - 32;                       // 0..31
+      const uint32_t maskh = (1u << wh) - 1u;           // wh == 0 -> 0
+      x.v[0] = (((uint64_t)(n1 & maskh) << 32) | n0) + base;
+      // drop w bits: one dword, then wh more
+      const uint32_t m0 = __builtin_amdgcn_alignbit(n2, n1, wh);
+      const uint32_t m1 = __builtin_amdgcn_alignbit(n3, n2, wh);
+      x.v[1] = (((uint64_t)(m1 & maskh) << 32) | m0) + base;
+    }
+  } else {
+#pragma unroll
+    for (uint32_t j = 0; j < V; ++j) {
+      x.v[j] = (T)((T)(n0 & mask32) + base);
+      n0 = __builtin_amdgcn_alignbit(n1, n0, w);
+      n1 = __builtin_amdgcn_alignbit(n2, n1, w);
+      n2 = __builtin_amdgcn_alignbit(n3, n2, w);
+      n3 >>= w;
+    }
+  }
+}
+
+template <int ES>
+__device__ __forceinline__ void body_materialize_fbw(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
   using T = typename ElemT<ES>::type;
   constexpr uint32_t V = 16 / ES;
   constexpr uint32_t TE = kTileBytes / ES;
-  const TileRef tr = a.tiles[blockIdx.x];
-  const NodeDesc& nd = a.nodes[tr.node];
   const uint64_t rows = nd.rows;
-  const uint64_t start = (uint64_t)tr.tile * TE;
+  const uint64_t start = (uint64_t)tile * TE;
   const uint32_t w = nd.c0.width;           // wave uniform
   const T base = (T)nd.c0.base;
   T* dst = reinterpret_cast<T*>(self_ptr(nd, a)) + start;
@@ -253,123 +466,145 @@ __global__ __launch_bounds__(256) void k_materialize_fbw(KArgs a) {
   const uint8_t* tile_src = a.arena + nd.c0.off + (tile_bit >> 3);
   const uint32_t tile_sh = (uint32_t)tile_bit & 7u;
   const uint32_t tile_rows = rows - start < TE ? (uint32_t)(rows - start) : TE;
-  const uint32_t mask32 = w >= 32 ? 0xFFFFFFFFu : ((1u << w) - 1u);
+  if (V * w <= 16) {
+    // Narrow rows: neighbouring lanes' windows start at most two bytes apart and
+    // one (misaligned) 16-byte load per lane runs at full rate.  All four loads
+    // are issued before the first store; vectors past the end of the tile
+    // re-read the tile's last vector (in bounds) and are not stored.
+    const uint32_t last_q = ((tile_rows - 1) / V) * V;
+    u32x4 win[4];
+#pragma unroll
+    for (uint32_t it = 0; it < 4; ++it) {
+      uint32_t q = (it * kBlock + threadIdx.x) * V;  // first row of this lane's vector, tile relative
+      q = q < last_q ? q : last_q;
+      const uint32_t lb = tile_sh + q * w;
+      __builtin_memcpy(&win[it], tile_src + (lb >> 3), 16);  // packed bytes + slop keep this in bounds
+    }
+#pragma unroll
+    for (uint32_t it = 0; it < 4; ++it) {
+      const uint32_t q = (it * kBlock + threadIdx.x) * V;
+      const uint32_t qc = q < last_q ? q : last_q;
+      const uint32_t S = (tile_sh + qc * w) & 7u;
+      const u32x4 d = win[it];
+      Vec16<ES> x;
+      unpack_window<ES>(__builtin_amdgcn_alignbit(d.y, d.x, S), __builtin_amdgcn_alignbit(d.z, d.y, S),
+                        __builtin_amdgcn_alignbit(d.w, d.z, S), d.w >> S, w, base, x);
+      if (q < tile_rows) store_vec<ES>(dst, q, tile_rows, x);
+    }
+    return;
+  }
+  // Wide rows: stage the tile's packed bytes (at most 16144) in LDS.
+  u32x4* stage = reinterpret_cast<u32x4*>(smem);
+  const uint32_t mis = stage_tile<4>(tile_src, (tile_sh + tile_rows * w + 7u) >> 3, stage);
+  __syncthreads();
+  const uint32_t* s32 = reinterpret_cast<const uint32_t*>(stage);
+  const uint32_t bit0 = mis * 8u + tile_sh;
 #pragma unroll
   for (uint32_t it = 0; it < 4; ++it) {
-    const uint32_t q = (it * kBlock + threadIdx.x) * V;  // first row of this lane's vector, tile relative
-    if (q >= tile_rows) break;
-    const uint32_t lb = tile_sh + q * w;                 // < 16384*62 + 8: 20 bits
-    u32x4 d;
-    __builtin_memcpy(&d, tile_src + (lb >> 3), 16);      // packed bytes + 7 bytes slop keep this in bounds
-    const uint32_t S = lb & 7u;
-    // normalise: n = window >> S
-    uint32_t n0 = __builtin_amdgcn_alignbit(d.y, d.x, S);
-    uint32_t n1 = __builtin_amdgcn_alignbit(d.z, d.y, S);
-    uint32_t n2 = __builtin_amdgcn_alignbit(d.w, d.z, S);
-    uint32_t n3 = d.w >> S;
-    if constexpr (ES == 8) {
-      if (w == 63) n3 = __builtin_amdgcn_alignbit(ldu32(tile_src + (lb >> 3) + 16), d.w, S);  // bits 128..131
+    const uint32_t q = (it * kBlock + threadIdx.x) * V;
+    if (q < tile_rows) {
+      uint32_t n0, n1, n2, n3;
+      lds_window(s32, bit0 + q * w, n0, n1, n2, n3);
+      Vec16<ES> x;
+      unpack_window<ES>(n0, n1, n2, n3, w, base, x);
+      store_vec<ES>(dst, q, tile_rows, x);
     }
-    Vec16<ES> x;
-    if constexpr (ES == 8) {
-      if (w < 32) {
-        const uint32_t v0 = n0 & mask32;
-        n0 = __builtin_amdgcn_alignbit(n1, n0, w);
-        x.v[0] = (uint64_t)v0 + base;
-        x.v[1] = (uint64_t)(n0 & mask32) + base;
-      } else {
-        const uint32_t wh = w - 32;                       // 0..30
-        const uint32_t maskh = (1u << wh) - 1u;           // wh == 0 -> 0
-        x.v[0] = (((uint64_t)(n1 & maskh) << 32) | n0) + base;
-        // drop w bits: one dword, then wh more
-        const uint32_t m0 = __builtin_amdgcn_alignbit(n2, n1, wh);
-        const uint32_t m1 = __builtin_amdgcn_alignbit(n3, n2, wh);
-        x.v[1] = (((uint64_t)(m1 & maskh) << 32) | m0) + base;
-      }
-    } else {
-#pragma unroll
-      for (uint32_t j = 0; j < V; ++j) {
-        x.v[j] = (T)((T)(n0 & mask32) + base);
-        n0 = __builtin_amdgcn_alignbit(n1, n0, w);
-        n1 = __builtin_amdgcn_alignbit(n2, n1, w);
-        n2 = __builtin_amdgcn_alignbit(n3, n2, w);
-        n3 >>= w;
-      }
-    }
-    store_vec<ES>(dst, q, tile_rows, x);
   }
 }
 
+// Byte-aligned elements (Trivial, or FixedBitWidth at the full width): a copy
+// (+ baseline) from an arbitrarily aligned source.
 template <int ES>
-__global__ __launch_bounds__(256) void k_materialize_raw(KArgs a) {
+__device__ __forceinline__ void body_materialize_raw(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
   using T = typename ElemT<ES>::type;
   constexpr uint32_t V = 16 / ES;
   constexpr uint32_t TE = kTileBytes / ES;
-  const TileRef tr = a.tiles[blockIdx.x];
-  const NodeDesc& nd = a.nodes[tr.node];
   const uint64_t rows = nd.rows;
-  const uint64_t start = (uint64_t)tr.tile * TE;
+  const uint64_t start = (uint64_t)tile * TE;
   const T base = nd.c0.kind == COL_FBW ? (T)nd.c0.base : (T)0;
   const uint8_t* src = a.arena + nd.c0.off + start * ES;
   T* dst = reinterpret_cast<T*>(self_ptr(nd, a)) + start;
   const uint32_t tile_rows = rows - start < TE ? (uint32_t)(rows - start) : TE;
+  Vec16<ES> x[4];
+  if ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+    // aligned source: four 16-byte loads in flight before the first store; lanes
+    // without a full vector re-read the tile's first 16 bytes (in bounds: arena slop)
+#pragma unroll
+    for (uint32_t it = 0; it < 4; ++it) {
+      const uint32_t q = (it * kBlock + threadIdx.x) * V;
+      x[it].q = *reinterpret_cast<const u32x4*>(q + V <= tile_rows ? src + q * (uint32_t)ES : src);
+    }
+  } else {
+    u32x4* stage = reinterpret_cast<u32x4*>(smem);
+    const uint32_t mis = stage_tile<5>(src, tile_rows * (uint32_t)ES, stage);  // up to 16 KiB + 19 bytes
+    __syncthreads();
+    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(stage);
+#pragma unroll
+    for (uint32_t it = 0; it < 4; ++it) {
+      const uint32_t q = (it * kBlock + threadIdx.x) * V;
+      const uint32_t qc = q + V <= tile_rows ? q : 0;
+      uint32_t n0, n1, n2, n3;
+      lds_window(s32, mis * 8u + qc * (uint32_t)(8 * ES), n0, n1, n2, n3);
+      x[it].q = make_u32x4(n0, n1, n2, n3);
+    }
+  }
 #pragma unroll
   for (uint32_t it = 0; it < 4; ++it) {
     const uint32_t q = (it * kBlock + threadIdx.x) * V;
-    if (q >= tile_rows) break;
-    Vec16<ES> x;
     if (q + V <= tile_rows) {
-      __builtin_memcpy(&x.q, src + (size_t)q * ES, 16);
-    } else {
-      x.q = make_u32x4(0, 0, 0, 0);
-#pragma unroll
-      for (uint32_t j = 0; j < V; ++j)
-        if (q + j < tile_rows) __builtin_memcpy(&x.v[j], src + (size_t)(q + j) * ES, ES);
+      vec_add_base<ES>(x[it], base);
+      store_vec<ES>(dst, q, tile_rows, x[it]);
+    } else if (q < tile_rows) {  // the column's partial last vector
+#pragma unroll 1
+      for (uint32_t r = q; r < tile_rows; ++r) dst[r] = (T)(ld_elem<ES>(src + r * (uint32_t)ES) + base);
     }
-#pragma unroll
-    for (uint32_t j = 0; j < V; ++j) x.v[j] = (T)(x.v[j] + base);
-    store_vec<ES>(dst, q, tile_rows, x);
   }
 }
 
 template <int ES>
-__global__ __launch_bounds__(256) void k_materialize(KArgs a) {
+__device__ __forceinline__ void body_materialize(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t*) {
   using T = typename ElemT<ES>::type;
   constexpr uint32_t V = 16 / ES;
   constexpr uint32_t TE = kTileBytes / ES;
-  const TileRef tr = a.tiles[blockIdx.x];
-  const NodeDesc& nd = a.nodes[tr.node];
-  const ColRef src = nd.c0;
   const uint64_t rows = nd.rows;
-  const uint64_t start = (uint64_t)tr.tile * TE;
+  const uint64_t start = (uint64_t)tile * TE;
   T* dst = reinterpret_cast<T*>(self_ptr(nd, a));
-#pragma unroll
-  for (uint32_t it = 0; it < 4; ++it) {
-    const uint64_t e0 = start + (uint64_t)(it * kBlock + threadIdx.x) * V;
-    if (e0 >= rows) break;
+  const uint32_t tile_rows = rows - start < TE ? (uint32_t)(rows - start) : TE;
+  if (nd.c0.kind == COL_CONST) {  // ConstantEncoding: a fill
     Vec16<ES> x;
 #pragma unroll
-    for (uint32_t j = 0; j < V; ++j) x.v[j] = (T)col_get(src, a, e0 + j < rows ? e0 + j : rows - 1);
-    store_vec<ES>(dst, e0, rows, x);
+    for (uint32_t j = 0; j < V; ++j) x.v[j] = (T)nd.c0.base;
+#pragma unroll
+    for (uint32_t it = 0; it < 4; ++it) {
+      const uint32_t q0 = (it * kBlock + threadIdx.x) * V;
+      if (q0 < tile_rows) store_vec<ES>(dst + start, q0, tile_rows, x);
+    }
+    return;
   }
+  // anything the specialised variants do not take: element by element
+#pragma unroll 1
+  for (uint32_t q = threadIdx.x; q < tile_rows; q += kBlock) dst[start + q] = (T)col_get(nd.c0, a, start + q);
 }
 
 // ----------------------------------------------------------- K_BITS_TO_BYTES
 // Bool bitmap -> one byte per row, what Encoding::materialize yields for bool
 // (TrivialEncoding<bool>::materialize, encodings/TrivialEncoding.cpp:329-368).
-__global__ __launch_bounds__(256) void k_bits_to_bytes(KArgs a) {
-  const TileRef tr = a.tiles[blockIdx.x];
-  const NodeDesc& nd = a.nodes[tr.node];
+__device__ __forceinline__ void body_bits_to_bytes(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t*) {
   const ColRef src = nd.c0;
   const uint64_t rows = nd.rows;
-  const uint64_t start = (uint64_t)tr.tile * kTileBytes;
+  const uint64_t start = (uint64_t)tile * kTileBytes;
   uint8_t* dst = self_ptr(nd, a);
+  uint64_t word[4];
+#pragma unroll
+  for (uint32_t it = 0; it < 4; ++it) {
+    const uint64_t e0 = start + (uint64_t)(it * kBlock + threadIdx.x) * 16;
+    word[it] = bits_word(src, a, (e0 < rows ? e0 : rows - 1) >> 6);  // clamped: every lane loads
+  }
 #pragma unroll
   for (uint32_t it = 0; it < 4; ++it) {
     const uint64_t e0 = start + (uint64_t)(it * kBlock + threadIdx.x) * 16;
     if (e0 >= rows) break;
-    const uint64_t word = bits_word(src, a, e0 >> 6);
-    const uint32_t b16 = (uint32_t)(word >> (e0 & 63)) & 0xFFFFu;
+    const uint32_t b16 = (uint32_t)(word[it] >> (e0 & 63)) & 0xFFFFu;
     Vec16<1> x;
     const uint64_t lo = spread8(b16), hi = spread8(b16 >> 8);
     x.q.x = (uint32_t)lo; x.q.y = (uint32_t)(lo >> 32);
@@ -379,33 +614,35 @@ __global__ __launch_bounds__(256) void k_bits_to_bytes(KArgs a) {
 }
 
 // -------------------------------------------------------------- tile reduces
-__global__ __launch_bounds__(256) void k_reduce_sum(KArgs a) {
-  __shared__ uint32_t tmp[4];
-  const TileRef tr = a.tiles[blockIdx.x];
-  const NodeDesc& nd = a.nodes[tr.node];
-  const ColRef src = nd.c0;
-  const uint64_t n = src.rows;
-  const uint64_t e0 = (uint64_t)tr.tile * kScanTile + (uint64_t)threadIdx.x * 8;
+__device__ __forceinline__ void body_reduce_sum(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem);
+  const uint64_t n = nd.c0.rows;
+  const uint64_t t0 = (uint64_t)tile * kScanTile;            // < n: the tile exists
+  const uint32_t tn = n - t0 < kScanTile ? (uint32_t)(n - t0) : kScanTile;
+  const uint32_t r0 = threadIdx.x * 8;
   uint32_t s = 0;
+  with_reader<4>(nd.c0, a, [&](auto rd) {
+    const auto src = rd.view(t0);
+    uint32_t v[8];
 #pragma unroll
-  for (uint32_t j = 0; j < 8; ++j)
-    if (e0 + j < n) s += (uint32_t)col_get(src, a, e0 + j);
+    for (uint32_t j = 0; j < 8; ++j) v[j] = src.at(r0 + j < tn ? r0 + j : tn - 1);
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) s += r0 + j < tn ? v[j] : 0u;
+  });
   const uint32_t tot = block_sum(s, tmp);
-  if (threadIdx.x == 0) a.parts[nd.part_base + tr.tile] = tot;
+  if (threadIdx.x == 0) a.parts[nd.part_base + tile] = tot;
 }
 
-// Tile = nd.tile_rows rows of the selection bitmap (a multiple of 64, <= 16384).
-__global__ __launch_bounds__(256) void k_reduce_popc(KArgs a) {
-  __shared__ uint32_t tmp[4];
-  const TileRef tr = a.tiles[blockIdx.x];
-  const NodeDesc& nd = a.nodes[tr.node];
+// Tile = nd.aux2 rows of the selection bitmap (a multiple of 64, <= 16384).
+__device__ __forceinline__ void body_reduce_popc(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem);
   const uint32_t words = (uint32_t)(nd.aux2 >> 6);  // tile rows / 64
-  const uint64_t w = (uint64_t)tr.tile * words + threadIdx.x;
+  const uint64_t w = (uint64_t)tile * words + threadIdx.x;
   uint32_t s = 0;
   if (threadIdx.x < words && w * 64 < nd.sel.rows)
     s = (uint32_t)__popcll(bits_word_masked(nd.sel, a, w, (nd.flags & NF_INVERT_SEL) != 0));
   const uint32_t tot = block_sum(s, tmp);
-  if (threadIdx.x == 0) a.parts[nd.part_base + tr.tile] = tot;
+  if (threadIdx.x == 0) a.parts[nd.part_base + tile] = tot;
 }
 
 // A varint starts at payload byte b when b == 0 or byte b-1 has its high bit
@@ -425,26 +662,22 @@ __device__ __forceinline__ uint32_t varint_start_mask16(const uint8_t* payload, 
     if (b0 + j < len && !(prev[j] & 0x80)) m |= 1u << j;
   return m;
 }
-__global__ __launch_bounds__(256) void k_reduce_varint(KArgs a) {
-  __shared__ uint32_t tmp[4];
-  const TileRef tr = a.tiles[blockIdx.x];
-  const NodeDesc& nd = a.nodes[tr.node];
+__device__ __forceinline__ void body_reduce_varint(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem);
   const uint8_t* payload = a.arena + nd.c0.off;
   const uint64_t len = nd.aux2;
-  const uint64_t b0 = (uint64_t)tr.tile * kVarintTile + (uint64_t)threadIdx.x * 16;
+  const uint64_t b0 = (uint64_t)tile * kVarintTile + (uint64_t)threadIdx.x * 16;
   uint32_t s = 0;
   if (b0 < len) s = (uint32_t)__popc(varint_start_mask16(payload, len, b0));
   const uint32_t tot = block_sum(s, tmp);
-  if (threadIdx.x == 0) a.parts[nd.part_base + tr.tile] = tot;
+  if (threadIdx.x == 0) a.parts[nd.part_base + tile] = tot;
 }
 
 // -------------------------------------------------------------- K_SCAN_TILES
 // One workgroup per node: exclusive scan of the node's tile partials in place,
 // grand total to totals[total_idx].
-__global__ __launch_bounds__(256) void k_scan_tiles(KArgs a) {
-  __shared__ uint32_t tmp[4];
-  const TileRef tr = a.tiles[blockIdx.x];
-  const NodeDesc& nd = a.nodes[tr.node];
+__device__ __forceinline__ void body_scan_tiles(const KArgs& a, const NodeDesc& nd, uint32_t, uint8_t* smem) {
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem);
   uint32_t* p = a.parts + nd.part_base;
   const uint32_t n = nd.n_parts;
   uint32_t carry = 0;
@@ -461,25 +694,32 @@ __global__ __launch_bounds__(256) void k_scan_tiles(KArgs a) {
 
 // ---------------------------------------------------------------- K_RLE_ENDS
 // ends[k] = len[0] + ... + len[k]; flags zero-length runs in totals[total_idx+1].
-__global__ __launch_bounds__(256) void k_rle_ends(KArgs a) {
-  __shared__ uint32_t tmp[4];
-  const TileRef tr = a.tiles[blockIdx.x];
-  const NodeDesc& nd = a.nodes[tr.node];
-  const ColRef src = nd.c0;
-  const uint64_t n = src.rows;
-  const uint64_t e0 = (uint64_t)tr.tile * kScanTile + (uint64_t)threadIdx.x * 8;
+__device__ __forceinline__ void body_rle_ends(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem);
+  const uint64_t n = nd.c0.rows;
+  const uint64_t e0 = (uint64_t)tile * kScanTile + (uint64_t)threadIdx.x * 8;
   uint32_t v[8];
   uint32_t s = 0;
   bool zero = false;
+  {
+    const uint64_t t0 = (uint64_t)tile * kScanTile;
+    const uint32_t tn = n - t0 < kScanTile ? (uint32_t)(n - t0) : kScanTile;
+    const uint32_t r0 = threadIdx.x * 8;
+    with_reader<4>(nd.c0, a, [&](auto rd) {
+      const auto src = rd.view(t0);
+#pragma unroll
+      for (uint32_t j = 0; j < 8; ++j) v[j] = src.at(r0 + j < tn ? r0 + j : tn - 1);
+    });
+  }
 #pragma unroll
   for (uint32_t j = 0; j < 8; ++j) {
-    const uint32_t len = e0 + j < n ? (uint32_t)col_get(src, a, e0 + j) : 0;
+    const uint32_t len = e0 + j < n ? v[j] : 0;
     zero |= (e0 + j < n) && len == 0;
     s += len;
     v[j] = s;
   }
   uint32_t total;
-  const uint32_t ex = block_excl_scan(s, tmp, total) + a.parts[nd.part_base + tr.tile];
+  const uint32_t ex = block_excl_scan(s, tmp, total) + a.parts[nd.part_base + tile];
   uint32_t* ends = reinterpret_cast<uint32_t*>(a.work + nd.aux_off);
   if (e0 + 8 <= n) {
     *reinterpret_cast<u32x4*>(ends + e0) = make_u32x4(v[0] + ex, v[1] + ex, v[2] + ex, v[3] + ex);
@@ -496,9 +736,6 @@ __global__ __launch_bounds__(256) void k_rle_ends(KArgs a) {
 // RLEEncoding::materialize (encodings/RLEEncoding.h:879-897): row p takes the
 // value of run k = #{ends <= p}.  Per tile the run boundaries become a bitmap
 // in LDS and k is a popcount prefix, so stores stay lane contiguous.
-struct RunRange {
-  uint32_t k0, k1;  // runs overlapping the tile: [k0, k1], both < R
-};
 __device__ __forceinline__ void find_run_range(const uint32_t* ends, uint32_t R, uint64_t p0, uint64_t p1, uint32_t* s_k) {
   // wave 0: first run ending after p0; wave 1: first run ending at/after p1
   if (wave_id() == 0) {
@@ -521,25 +758,23 @@ __device__ __forceinline__ uint32_t run_of_row(const uint32_t* ends, uint32_t lo
 }
 
 template <int ES>
-__global__ __launch_bounds__(256) void k_rle_expand(KArgs a) {
+__device__ __forceinline__ void body_rle_expand(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
   using T = typename ElemT<ES>::type;
   constexpr uint32_t V = 16 / ES;
   constexpr uint32_t TE = kTileBytes / ES;
   constexpr uint32_t W = TE / 64;
-  __shared__ uint64_t s_bits[W];
-  __shared__ uint32_t s_pref[W];
-  __shared__ T s_vals[TE];
-  __shared__ uint32_t s_k[2];
-  __shared__ uint32_t tmp[4];
-  const TileRef tr = a.tiles[blockIdx.x];
-  const NodeDesc& nd = a.nodes[tr.node];
+  T* s_vals = reinterpret_cast<T*>(smem);                                  // TE elements = kTileBytes
+  uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem + kTileBytes);        // W <= 256 words
+  uint32_t* s_pref = reinterpret_cast<uint32_t*>(smem + kTileBytes + 2048);  // W words
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + kTileBytes + 3072);     // 4 words
+  uint32_t* s_k = tmp + 4;                                                   // 2 words
   const uint64_t rows = nd.rows;
   const uint32_t R = nd.c0.rows;
-  const uint64_t p0 = (uint64_t)tr.tile * TE;
+  const uint64_t p0 = (uint64_t)tile * TE;
   const uint64_t p1 = p0 + TE < rows ? p0 + TE : rows;
   T* dst = reinterpret_cast<T*>(self_ptr(nd, a));
   const uint32_t* ends = reinterpret_cast<const uint32_t*>(a.work + nd.aux_off);
-  if (tr.tile == 0 && threadIdx.x == 0 && a.totals[nd.total_idx] != nd.rows) atomicOr(a.status, ST_RLE_SUM_MISMATCH);
+  if (tile == 0 && threadIdx.x == 0 && a.totals[nd.total_idx] != nd.rows) atomicOr(a.status, ST_RLE_SUM_MISMATCH);
   if (R == 0) {  // malformed: rows without runs
     for (uint32_t it = 0; it < 4; ++it) {
       const uint64_t e0 = p0 + (uint64_t)(it * kBlock + threadIdx.x) * V;
@@ -564,7 +799,11 @@ __global__ __launch_bounds__(256) void k_rle_expand(KArgs a) {
         atomicOr(&bits32[q >> 5], 1u << (q & 31));
       }
     }
-    for (uint32_t j = threadIdx.x; j < nruns; j += kBlock) s_vals[j] = (T)col_get(nd.c1, a, k0 + j);
+    with_reader<ES>(nd.c1, a, [&](auto rd) {
+      const auto src = rd.view(k0);
+#pragma unroll 2
+      for (uint32_t j = threadIdx.x; j < nruns; j += kBlock) s_vals[j] = src.at(j);
+    });
     __syncthreads();
     uint32_t pc = threadIdx.x < W ? (uint32_t)__popcll(s_bits[threadIdx.x]) : 0;
     uint32_t total;
@@ -580,24 +819,18 @@ __global__ __launch_bounds__(256) void k_rle_expand(KArgs a) {
       const uint32_t b = q0 & 63;
       uint32_t r = s_pref[q0 >> 6] + (uint32_t)__popcll(word & ((2ull << b) - 1ull));
       Vec16<ES> x;
+      x.q = make_u32x4(0, 0, 0, 0);
 #pragma unroll
       for (uint32_t j = 0; j < V; ++j) {
         if (j > 0) r += (uint32_t)(word >> (b + j)) & 1u;
-        x.v[j] = s_vals[r < nruns ? r : nruns - 1];
+        vec_set<ES>(x, j, s_vals[r < nruns ? r : nruns - 1]);
       }
       store_vec<ES>(dst, e0, rows, x);
     }
   } else {
-    for (uint32_t it = 0; it < 4; ++it) {
-      const uint64_t e0 = p0 + (uint64_t)(it * kBlock + threadIdx.x) * V;
-      if (e0 >= rows) break;
-      Vec16<ES> x;
-      for (uint32_t j = 0; j < V; ++j) {
-        const uint64_t p = e0 + j < rows ? e0 + j : rows - 1;
-        x.v[j] = (T)col_get(nd.c1, a, run_of_row(ends, k0, k1, (uint32_t)p));
-      }
-      store_vec<ES>(dst, e0, rows, x);
-    }
+    // zero-length runs, or more runs than the LDS stage holds: every row finds its run by binary search
+#pragma unroll 1
+    for (uint64_t p = p0 + threadIdx.x; p < p1; p += kBlock) dst[p] = (T)col_get(nd.c1, a, run_of_row(ends, k0, k1, (uint32_t)p));
   }
 }
 
@@ -607,22 +840,20 @@ __device__ __forceinline__ uint64_t prefix_xor64(uint64_t x) {
   x ^= x << 1; x ^= x << 2; x ^= x << 4; x ^= x << 8; x ^= x << 16; x ^= x << 32;
   return x;
 }
-__global__ __launch_bounds__(256) void k_rle_expand_bool(KArgs a) {
+__device__ __forceinline__ void body_rle_expand_bool(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
   constexpr uint32_t W = kBitTileWords;
-  __shared__ uint64_t s_bits[W];
-  __shared__ uint32_t s_k[2];
-  __shared__ uint32_t tmp[4];
-  const TileRef tr = a.tiles[blockIdx.x];
-  const NodeDesc& nd = a.nodes[tr.node];
+  uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem);            // 256 words
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + 2048);
+  uint32_t* s_k = tmp + 4;
   const uint64_t rows = nd.rows;
   const uint32_t R = nd.c0.rows;
-  const uint64_t p0 = (uint64_t)tr.tile * kBitTileRows;
+  const uint64_t p0 = (uint64_t)tile * kBitTileRows;
   const uint64_t p1 = p0 + kBitTileRows < rows ? p0 + kBitTileRows : rows;
   uint64_t* dst = reinterpret_cast<uint64_t*>(a.work + nd.self.off);
   const uint32_t* ends = reinterpret_cast<const uint32_t*>(a.work + nd.aux_off);
   const uint64_t firstmask = (nd.flags & NF_FIRST_TRUE) ? ~0ull : 0ull;
-  const uint64_t w = (uint64_t)tr.tile * W + threadIdx.x;  // output word of this thread
-  if (tr.tile == 0 && threadIdx.x == 0 && a.totals[nd.total_idx] != nd.rows) atomicOr(a.status, ST_RLE_SUM_MISMATCH);
+  const uint64_t w = (uint64_t)tile * W + threadIdx.x;  // output word of this thread
+  if (tile == 0 && threadIdx.x == 0 && a.totals[nd.total_idx] != nd.rows) atomicOr(a.status, ST_RLE_SUM_MISMATCH);
   if (R == 0) {
     if (w * 64 < rows) dst[w] = 0;
     return;
@@ -656,7 +887,7 @@ __global__ __launch_bounds__(256) void k_rle_expand_bool(KArgs a) {
   } else {
     // zero-length runs present: resolve every row by binary search, one word per wave pass
     for (uint32_t i = wave_id(); i < W; i += 4) {
-      const uint64_t ww = (uint64_t)tr.tile * W + i;
+      const uint64_t ww = (uint64_t)tile * W + i;
       if (ww * 64 >= rows) break;
       const uint64_t p = ww * 64 + lane_id();
       bool bit = false;
@@ -673,40 +904,49 @@ __global__ __launch_bounds__(256) void k_rle_expand_bool(KArgs a) {
 // ------------------------------------------------------------- K_SPARSE_BITS
 // SparseBoolEncoding::materializeBoolsAsBits (encodings/SparseBoolEncoding.cpp:121-142):
 // every row is !sparseValue except the listed (ascending) positions.
-__global__ __launch_bounds__(256) void k_sparse_bits(KArgs a) {
+__device__ __forceinline__ void body_sparse_bits(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
   constexpr uint32_t W = kBitTileWords;
-  __shared__ uint64_t s_bits[W];
-  __shared__ uint32_t s_k[2];
-  const TileRef tr = a.tiles[blockIdx.x];
-  const NodeDesc& nd = a.nodes[tr.node];
+  uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem);
+  uint32_t* s_k = reinterpret_cast<uint32_t*>(smem + 2048);
   const uint64_t rows = nd.rows;
-  const ColRef idx = nd.c0;
-  const uint32_t K = idx.rows;
-  const uint64_t p0 = (uint64_t)tr.tile * kBitTileRows;
+  const uint32_t K = nd.c0.rows;
+  const uint64_t p0 = (uint64_t)tile * kBitTileRows;
   const uint64_t p1 = p0 + kBitTileRows < rows ? p0 + kBitTileRows : rows;
   uint64_t* dst = reinterpret_cast<uint64_t*>(a.work + nd.self.off);
-  if (wave_id() == 0) {
-    const uint32_t key = (uint32_t)p0;
-    uint32_t k = wave_first_true(K, [&](uint32_t i) { return (uint32_t)col_get(idx, a, i) >= key; });
-    if (lane_id() == 0) s_k[0] = k;
-  } else if (wave_id() == 1) {
-    const uint32_t key = (uint32_t)p1;
-    uint32_t k = wave_first_true(K, [&](uint32_t i) { return (uint32_t)col_get(idx, a, i) >= key; });
-    if (lane_id() == 0) s_k[1] = k;
-  }
-  s_bits[threadIdx.x] = 0;
-  __syncthreads();
-  const uint32_t lo = s_k[0], hi = s_k[1];
-  uint32_t* bits32 = reinterpret_cast<uint32_t*>(s_bits);
-  for (uint32_t j = lo + threadIdx.x; j < hi; j += kBlock) {
-    const uint64_t pos = (uint32_t)col_get(idx, a, j);
-    if (pos >= p0 && pos < p1) {
-      const uint32_t q = (uint32_t)(pos - p0);
-      atomicOr(&bits32[q >> 5], 1u << (q & 31));
+  with_reader<4>(nd.c0, a, [&](auto rd) {
+    if (wave_id() == 0) {
+      const uint32_t key = (uint32_t)p0;
+      uint32_t k = wave_first_true(K, [&](uint32_t i) { return rd.get(i) >= key; });
+      if (lane_id() == 0) s_k[0] = k;
+    } else if (wave_id() == 1) {
+      const uint32_t key = (uint32_t)p1;
+      uint32_t k = wave_first_true(K, [&](uint32_t i) { return rd.get(i) >= key; });
+      if (lane_id() == 0) s_k[1] = k;
     }
-  }
+    s_bits[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t lo = s_k[0], hi = s_k[1];
+    uint32_t* bits32 = reinterpret_cast<uint32_t*>(s_bits);
+    // four positions per thread in flight per round
+    for (uint32_t j0 = lo + threadIdx.x; j0 < hi; j0 += 4 * kBlock) {
+      uint32_t pos[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t j = j0 + u * kBlock;
+        pos[u] = rd.get(j < hi ? j : hi - 1);
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t j = j0 + u * kBlock;
+        if (j < hi && pos[u] >= p0 && pos[u] < p1) {
+          const uint32_t q = (uint32_t)(pos[u] - p0);
+          atomicOr(&bits32[q >> 5], 1u << (q & 31));
+        }
+      }
+    }
+  });
   __syncthreads();
-  const uint64_t w = (uint64_t)tr.tile * W + threadIdx.x;
+  const uint64_t w = (uint64_t)tile * W + threadIdx.x;
   if (w * 64 < rows) {
     uint64_t v = s_bits[threadIdx.x];
     if (!(nd.flags & NF_SPARSE_VALUE)) v = ~v;
@@ -720,24 +960,29 @@ __global__ __launch_bounds__(256) void k_sparse_bits(KArgs a) {
 // takes values[rank(i)] when its bit is set, physicalType() otherwise; and
 // MainlyConstantEncoding::materialize (encodings/MainlyConstantEncoding.h:208-253):
 // the common value where isCommon is set, otherValues[rank0(i)] elsewhere.
+//
+// Selected rows take consecutive ranks, so the per-lane loads below are lane
+// monotone (coalesced).  They are issued unconditionally at a clamped rank --
+// a lane whose bit is clear loads its successor's value and drops it -- which
+// keeps every load of the tile in flight at once.
 template <int ES>
-__global__ __launch_bounds__(256) void k_select_scatter(KArgs a) {
+__device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
   using T = typename ElemT<ES>::type;
   constexpr uint32_t V = 16 / ES;
   constexpr uint32_t TE = kTileBytes / ES;
   constexpr uint32_t W = TE / 64;
-  __shared__ uint64_t s_bits[W];
-  __shared__ uint32_t s_pref[W];
-  __shared__ uint32_t tmp[4];
-  const TileRef tr = a.tiles[blockIdx.x];
-  const NodeDesc& nd = a.nodes[tr.node];
+  constexpr uint32_t B = kBatch<ES>;
+  uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem);             // W <= 256 words
+  uint32_t* s_pref = reinterpret_cast<uint32_t*>(smem + 2048);       // W words
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + 3072);
   const uint64_t rows = nd.rows;
-  const uint64_t p0 = (uint64_t)tr.tile * TE;
+  const uint64_t p0 = (uint64_t)tile * TE;
+  const uint32_t tile_rows = rows - p0 < TE ? (uint32_t)(rows - p0) : TE;
   const bool invert = (nd.flags & NF_INVERT_SEL) != 0;
-  T* dst = reinterpret_cast<T*>(self_ptr(nd, a));
+  T* dst = reinterpret_cast<T*>(self_ptr(nd, a)) + p0;
   const uint32_t nvals = nd.c1.rows;
-  if (tr.tile == 0 && threadIdx.x == 0 && a.totals[nd.total_idx] != nvals) atomicOr(a.status, ST_SELECT_COUNT);
-  const uint64_t w = (uint64_t)tr.tile * W + threadIdx.x;
+  if (tile == 0 && threadIdx.x == 0 && a.totals[nd.total_idx] != nvals) atomicOr(a.status, ST_SELECT_COUNT);
+  const uint64_t w = (uint64_t)tile * W + threadIdx.x;
   uint64_t word = 0;
   if (threadIdx.x < W && w * 64 < rows) {
     word = bits_word_masked(nd.sel, a, w, invert);
@@ -747,43 +992,70 @@ __global__ __launch_bounds__(256) void k_select_scatter(KArgs a) {
   const uint32_t ex = block_excl_scan((uint32_t)__popcll(word), tmp, total);
   if (threadIdx.x < W) { s_bits[threadIdx.x] = word; s_pref[threadIdx.x] = ex; }
   __syncthreads();
-  const uint32_t base = a.parts[nd.part_base + tr.tile];
+  const uint32_t base = a.parts[nd.part_base + tile];
   const T fill = (T)nd.aux;
+  if (nvals == 0) {
 #pragma unroll
-  for (uint32_t it = 0; it < 4; ++it) {
-    const uint32_t q0 = (it * kBlock + threadIdx.x) * V;
-    const uint64_t e0 = p0 + q0;
-    if (e0 >= rows) break;
-    const uint64_t wd = s_bits[q0 >> 6];
-    const uint32_t b = q0 & 63;
-    uint32_t r = base + s_pref[q0 >> 6] + (uint32_t)__popcll(wd & ((1ull << b) - 1ull));
-    Vec16<ES> x;
+    for (uint32_t it = 0; it < 4; ++it) {
+      const uint32_t q0 = (it * kBlock + threadIdx.x) * V;
+      if (q0 >= tile_rows) break;
+      Vec16<ES> x;
 #pragma unroll
-    for (uint32_t j = 0; j < V; ++j) {
-      const uint32_t bit = (uint32_t)(wd >> (b + j)) & 1u;
-      T v = fill;
-      if (bit && nvals) v = (T)col_get(nd.c1, a, r < nvals ? r : nvals - 1);
-      x.v[j] = v;
-      r += bit;
+      for (uint32_t j = 0; j < V; ++j) x.v[j] = fill;
+      store_vec<ES>(dst, q0, tile_rows, x);
     }
-    store_vec<ES>(dst, e0, rows, x);
+    return;
   }
+  // values of this tile start at rank `first`; a lane's rank is first + rel,
+  // rel <= TE, clamped to the last value (corrupt counts cannot run past it)
+  const uint32_t first = base < nvals ? base : nvals - 1;
+  const uint32_t last_rel = nvals - 1 - first;
+  with_reader<ES>(nd.c1, a, [&](auto rd) {
+    const auto vals = rd.view(first);
+#pragma unroll
+    for (uint32_t ib = 0; ib < 4; ib += B) {
+      T x[B][V];
+      uint32_t bv[B];
+#pragma unroll
+      for (uint32_t u = 0; u < B; ++u) {
+        const uint32_t q0 = ((ib + u) * kBlock + threadIdx.x) * V;
+        const uint64_t wd = s_bits[q0 >> 6];
+        const uint32_t b = q0 & 63;
+        uint32_t r = s_pref[q0 >> 6] + (uint32_t)__popcll(wd & ((1ull << b) - 1ull));
+        const uint32_t bits = (uint32_t)(wd >> b);  // bit j = row q0 + j (b + V <= 64)
+        bv[u] = bits;
+#pragma unroll
+        for (uint32_t j = 0; j < V; ++j) {
+          x[u][j] = vals.at(r < last_rel ? r : last_rel);
+          r += (bits >> j) & 1u;
+        }
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < B; ++u) {
+        const uint32_t q0 = ((ib + u) * kBlock + threadIdx.x) * V;
+        if (q0 < tile_rows) {
+          Vec16<ES> o;
+#pragma unroll
+          for (uint32_t j = 0; j < V; ++j) o.v[j] = ((bv[u] >> j) & 1u) ? x[u][j] : fill;
+          store_vec<ES>(dst, q0, tile_rows, o);
+        }
+      }
+    }
+  });
 }
 
 // Nullable<bool>: scatter a bitmap of values by the selection bitmap.
 // Tile = 16384 rows; each wave resolves one output word per pass (lane = bit).
-__global__ __launch_bounds__(256) void k_select_bits(KArgs a) {
+__device__ __forceinline__ void body_select_bits(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
   constexpr uint32_t W = kBitTileWords;
-  __shared__ uint32_t s_pref[W];
-  __shared__ uint64_t s_bits[W];
-  __shared__ uint32_t tmp[4];
-  const TileRef tr = a.tiles[blockIdx.x];
-  const NodeDesc& nd = a.nodes[tr.node];
+  uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem);
+  uint32_t* s_pref = reinterpret_cast<uint32_t*>(smem + 2048);
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + 3072);
   const uint64_t rows = nd.rows;
   const uint32_t nvals = nd.c1.rows;
   uint64_t* dst = reinterpret_cast<uint64_t*>(a.work + nd.self.off);
-  if (tr.tile == 0 && threadIdx.x == 0 && a.totals[nd.total_idx] != nvals) atomicOr(a.status, ST_SELECT_COUNT);
-  const uint64_t w = (uint64_t)tr.tile * W + threadIdx.x;
+  if (tile == 0 && threadIdx.x == 0 && a.totals[nd.total_idx] != nvals) atomicOr(a.status, ST_SELECT_COUNT);
+  const uint64_t w = (uint64_t)tile * W + threadIdx.x;
   uint64_t word = 0;
   if (w * 64 < rows) {
     word = bits_word_masked(nd.sel, a, w, false);
@@ -793,9 +1065,9 @@ __global__ __launch_bounds__(256) void k_select_bits(KArgs a) {
   const uint32_t ex = block_excl_scan((uint32_t)__popcll(word), tmp, total);
   s_bits[threadIdx.x] = word; s_pref[threadIdx.x] = ex;
   __syncthreads();
-  const uint32_t base = a.parts[nd.part_base + tr.tile];
+  const uint32_t base = a.parts[nd.part_base + tile];
   for (uint32_t i = wave_id(); i < W; i += 4) {
-    const uint64_t ww = (uint64_t)tr.tile * W + i;
+    const uint64_t ww = (uint64_t)tile * W + i;
     if (ww * 64 >= rows) break;
     const uint64_t wd = s_bits[i];
     const uint32_t l = lane_id();
@@ -810,31 +1082,64 @@ __global__ __launch_bounds__(256) void k_select_bits(KArgs a) {
 
 // ------------------------------------------------------------- K_DICT_GATHER
 // DictionaryEncoding::materialize (encodings/DictionaryEncoding.h:227-236).
+// The planner hands the alphabet over as a plain element array (Trivial payload
+// in the arena, or materialised into work), so the gather is one load per row;
+// all index loads of a batch are issued first, then all gathers, then the stores.
 template <int ES>
-__global__ __launch_bounds__(256) void k_dict_gather(KArgs a) {
+__device__ __forceinline__ void body_dict_gather(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t*) {
   using T = typename ElemT<ES>::type;
   constexpr uint32_t V = 16 / ES;
   constexpr uint32_t TE = kTileBytes / ES;
-  const TileRef tr = a.tiles[blockIdx.x];
-  const NodeDesc& nd = a.nodes[tr.node];
+  constexpr uint32_t B = kBatch<ES>;
   const uint64_t rows = nd.rows;
-  const uint64_t start = (uint64_t)tr.tile * TE;
+  const uint64_t start = (uint64_t)tile * TE;
+  const uint32_t tile_rows = rows - start < TE ? (uint32_t)(rows - start) : TE;
   const uint32_t A = nd.c1.rows;
-  T* dst = reinterpret_cast<T*>(self_ptr(nd, a));
-  bool bad = false;
-#pragma unroll
-  for (uint32_t it = 0; it < 4; ++it) {
-    const uint64_t e0 = start + (uint64_t)(it * kBlock + threadIdx.x) * V;
-    if (e0 >= rows) break;
-    Vec16<ES> x;
-#pragma unroll
-    for (uint32_t j = 0; j < V; ++j) {
-      uint32_t ix = (uint32_t)col_get(nd.c0, a, e0 + j < rows ? e0 + j : rows - 1);
-      if (ix >= A) { bad = true; ix = A ? A - 1 : 0; }
-      x.v[j] = A ? (T)col_get(nd.c1, a, ix) : (T)0;
+  T* dst = reinterpret_cast<T*>(self_ptr(nd, a)) + start;
+  if (A == 0) {  // malformed: rows without an alphabet
+    for (uint32_t it = 0; it < 4; ++it) {
+      const uint32_t q0 = (it * kBlock + threadIdx.x) * V;
+      if (q0 >= tile_rows) break;
+      Vec16<ES> x; x.q = make_u32x4(0, 0, 0, 0);
+      store_vec<ES>(dst, q0, tile_rows, x);
     }
-    store_vec<ES>(dst, e0, rows, x);
+    if (threadIdx.x == 0) atomicOr(a.status, ST_DICT_INDEX_RANGE);
+    return;
   }
+  const Reader<RK_PTR, ES> alpha(nd.c1, a);
+  bool bad = false;
+  with_reader<4>(nd.c0, a, [&](auto rd) {
+    const auto idx = rd.view(start);
+#pragma unroll
+    for (uint32_t ib = 0; ib < 4; ib += B) {
+      uint32_t ix[B][V];
+#pragma unroll
+      for (uint32_t u = 0; u < B; ++u) {
+        const uint32_t q0 = ((ib + u) * kBlock + threadIdx.x) * V;
+#pragma unroll
+        for (uint32_t j = 0; j < V; ++j) ix[u][j] = idx.at(q0 + j < tile_rows ? q0 + j : tile_rows - 1);
+      }
+      T x[B][V];
+#pragma unroll
+      for (uint32_t u = 0; u < B; ++u)
+#pragma unroll
+        for (uint32_t j = 0; j < V; ++j) {
+          uint32_t i = ix[u][j];
+          if (i >= A) { bad = true; i = A - 1; }
+          x[u][j] = alpha.get(i);
+        }
+#pragma unroll
+      for (uint32_t u = 0; u < B; ++u) {
+        const uint32_t q0 = ((ib + u) * kBlock + threadIdx.x) * V;
+        if (q0 < tile_rows) {
+          Vec16<ES> o;
+#pragma unroll
+          for (uint32_t j = 0; j < V; ++j) o.v[j] = x[u][j];
+          store_vec<ES>(dst, q0, tile_rows, o);
+        }
+      }
+    }
+  });
   if (bad) atomicOr(a.status, ST_DICT_INDEX_RANGE);
 }
 
@@ -842,23 +1147,21 @@ __global__ __launch_bounds__(256) void k_dict_gather(KArgs a) {
 // VarintEncoding::materialize (encodings/VarintEncoding.h:119-140): LEB128,
 // low 7 bits first, + baseline (common/Varint.h:83-143 for the byte limits).
 template <int ES>
-__global__ __launch_bounds__(256) void k_varint_decode(KArgs a) {
+__device__ __forceinline__ void body_varint_decode(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
   using T = typename ElemT<ES>::type;
   constexpr uint32_t MAXB = ES == 4 ? 5 : 10;
-  __shared__ uint32_t tmp[4];
-  const TileRef tr = a.tiles[blockIdx.x];
-  const NodeDesc& nd = a.nodes[tr.node];
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem);
   const uint8_t* payload = a.arena + nd.c0.off;
   const uint64_t len = nd.aux2;
   const uint64_t rows = nd.rows;
   const T base = (T)nd.c0.base;
   T* dst = reinterpret_cast<T*>(self_ptr(nd, a));
-  const uint64_t b0 = (uint64_t)tr.tile * kVarintTile + (uint64_t)threadIdx.x * 16;
+  const uint64_t b0 = (uint64_t)tile * kVarintTile + (uint64_t)threadIdx.x * 16;
   uint32_t m = 0;
   if (b0 < len) m = varint_start_mask16(payload, len, b0);
   uint32_t total;
-  uint64_t rank = (uint64_t)a.parts[nd.part_base + tr.tile] + block_excl_scan((uint32_t)__popc(m), tmp, total);
-  if (tr.tile == 0 && threadIdx.x == 0 && a.totals[nd.total_idx] < nd.rows) atomicOr(a.status, ST_VARINT_COUNT);
+  uint64_t rank = (uint64_t)a.parts[nd.part_base + tile] + block_excl_scan((uint32_t)__popc(m), tmp, total);
+  if (tile == 0 && threadIdx.x == 0 && a.totals[nd.total_idx] < nd.rows) atomicOr(a.status, ST_VARINT_COUNT);
   while (m) {
     const uint32_t j = (uint32_t)__ffs((int)m) - 1u;
     m &= m - 1;
@@ -882,58 +1185,192 @@ __global__ __launch_bounds__(256) void k_varint_decode(KArgs a) {
 // TrivialEncoding<string_view>::materialize (encodings/TrivialEncoding.cpp:151-164):
 // view i = {running sum of lengths, length i}; emitted as uint64 = len << 32 | offset,
 // offset relative to the chunk's string region.
-__global__ __launch_bounds__(256) void k_string_views(KArgs a) {
-  __shared__ uint32_t tmp[4];
-  const TileRef tr = a.tiles[blockIdx.x];
-  const NodeDesc& nd = a.nodes[tr.node];
-  const ColRef src = nd.c0;
+__device__ __forceinline__ void body_string_views(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem);
   const uint64_t n = nd.rows;
-  const uint64_t e0 = (uint64_t)tr.tile * kScanTile + (uint64_t)threadIdx.x * 8;
+  const uint64_t e0 = (uint64_t)tile * kScanTile + (uint64_t)threadIdx.x * 8;
   uint32_t len[8];
   uint32_t s = 0;
+  {
+    const uint64_t t0 = (uint64_t)tile * kScanTile;
+    const uint32_t tn = n - t0 < kScanTile ? (uint32_t)(n - t0) : kScanTile;
+    const uint32_t r0 = threadIdx.x * 8;
+    with_reader<4>(nd.c0, a, [&](auto rd) {
+      const auto src = rd.view(t0);
+#pragma unroll
+      for (uint32_t j = 0; j < 8; ++j) len[j] = src.at(r0 + j < tn ? r0 + j : tn - 1);
+    });
+  }
 #pragma unroll
   for (uint32_t j = 0; j < 8; ++j) {
-    len[j] = e0 + j < n ? (uint32_t)col_get(src, a, e0 + j) : 0;
+    len[j] = e0 + j < n ? len[j] : 0;
     s += len[j];
   }
   uint32_t total;
-  uint32_t off = block_excl_scan(s, tmp, total) + a.parts[nd.part_base + tr.tile] + (uint32_t)nd.aux;
+  uint32_t off = block_excl_scan(s, tmp, total) + a.parts[nd.part_base + tile] + (uint32_t)nd.aux;
   uint64_t* dst = reinterpret_cast<uint64_t*>(self_ptr(nd, a));
+  uint64_t v[8];
 #pragma unroll
   for (uint32_t j = 0; j < 8; ++j) {
-    if (e0 + j < n) dst[e0 + j] = ((uint64_t)len[j] << 32) | off;
+    v[j] = ((uint64_t)len[j] << 32) | off;
     off += len[j];
   }
-  if (tr.tile == 0 && threadIdx.x == 0 && a.totals[nd.total_idx] > nd.aux2) atomicOr(a.status, ST_STRING_BYTES);
+  if (e0 + 8 <= n) {  // 64 contiguous bytes per thread
+#pragma unroll
+    for (uint32_t j = 0; j < 8; j += 2)
+      *reinterpret_cast<u32x4*>(dst + e0 + j) = make_u32x4((uint32_t)v[j], (uint32_t)(v[j] >> 32), (uint32_t)v[j + 1], (uint32_t)(v[j + 1] >> 32));
+  } else {
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j)
+      if (e0 + j < n) dst[e0 + j] = v[j];
+  }
+  if (tile == 0 && threadIdx.x == 0 && a.totals[nd.total_idx] > nd.aux2) atomicOr(a.status, ST_STRING_BYTES);
 }
 
 // -------------------------------------------------------------- K_COPY_BYTES
 // The blob copy TrivialEncoding<string_view> does into stringBufferFactory
 // memory (encodings/TrivialEncoding.cpp:129-135).
-__global__ __launch_bounds__(256) void k_copy_bytes(KArgs a) {
-  const TileRef tr = a.tiles[blockIdx.x];
-  const NodeDesc& nd = a.nodes[tr.node];
-  const uint8_t* src = a.arena + nd.aux_off;
-  uint8_t* dst = a.out + nd.self.off;
+__device__ __forceinline__ void body_copy_bytes(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
   const uint64_t n = nd.aux;
-  const uint64_t start = (uint64_t)tr.tile * kTileBytes;
+  const uint64_t start = (uint64_t)tile * kTileBytes;
+  const uint8_t* src = a.arena + nd.aux_off + start;
+  uint8_t* dst = a.out + nd.self.off + start;       // string regions start 16-byte aligned
+  const uint32_t tile_bytes = n - start < kTileBytes ? (uint32_t)(n - start) : kTileBytes;
+  u32x4 q[4];
+  if ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
 #pragma unroll
-  for (uint32_t it = 0; it < 4; ++it) {
-    const uint64_t b = start + (uint64_t)(it * kBlock + threadIdx.x) * 16;
-    if (b >= n) break;
-    if (b + 16 <= n) {
-      u32x4 q;
-      __builtin_memcpy(&q, src + b, 16);
-      *reinterpret_cast<u32x4*>(dst + b) = q;
-    } else {
-      for (uint64_t i = b; i < n; ++i) dst[i] = src[i];
+    for (uint32_t it = 0; it < 4; ++it) {
+      const uint32_t b = (it * kBlock + threadIdx.x) * 16;
+      q[it] = *reinterpret_cast<const u32x4*>(b + 16 <= tile_bytes ? src + b : src);  // arena slop keeps a short tile readable
+    }
+  } else {
+    u32x4* stage = reinterpret_cast<u32x4*>(smem);
+    const uint32_t mis = stage_tile<5>(src, tile_bytes, stage);
+    __syncthreads();
+    const uint32_t* s32 = reinterpret_cast<const uint32_t*>(stage);
+#pragma unroll
+    for (uint32_t it = 0; it < 4; ++it) {
+      const uint32_t b = (it * kBlock + threadIdx.x) * 16;
+      uint32_t n0, n1, n2, n3;
+      lds_window(s32, (mis + (b + 16 <= tile_bytes ? b : 0)) * 8u, n0, n1, n2, n3);
+      q[it] = make_u32x4(n0, n1, n2, n3);
     }
   }
+#pragma unroll
+  for (uint32_t it = 0; it < 4; ++it) {
+    const uint32_t b = (it * kBlock + threadIdx.x) * 16;
+    if (b + 16 <= tile_bytes) {
+      __builtin_nontemporal_store(q[it], reinterpret_cast<u32x4*>(dst + b));
+    } else if (b < tile_bytes) {
+#pragma unroll 1
+      for (uint32_t i = b; i < tile_bytes; ++i) dst[i] = src[i];
+    }
+  }
+}
+
+// ================================================================ dispatch
+// run_op<OP>: the body of operation OP = make_op(kernel, element size).
+template <uint32_t OP>
+__device__ __forceinline__ void run_op(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
+  constexpr uint32_t K = OP / 4;
+  constexpr int ES = 1 << (OP % 4);
+  if constexpr (K == K_MATERIALIZE) body_materialize<ES>(a, nd, tile, smem);
+  else if constexpr (K == K_MATERIALIZE_FBW) body_materialize_fbw<ES>(a, nd, tile, smem);
+  else if constexpr (K == K_MATERIALIZE_RAW) body_materialize_raw<ES>(a, nd, tile, smem);
+  else if constexpr (K == K_BITS_TO_BYTES) body_bits_to_bytes(a, nd, tile, smem);
+  else if constexpr (K == K_REDUCE_SUM) body_reduce_sum(a, nd, tile, smem);
+  else if constexpr (K == K_REDUCE_POPC) body_reduce_popc(a, nd, tile, smem);
+  else if constexpr (K == K_REDUCE_VARINT) body_reduce_varint(a, nd, tile, smem);
+  else if constexpr (K == K_SCAN_TILES) body_scan_tiles(a, nd, tile, smem);
+  else if constexpr (K == K_RLE_ENDS) body_rle_ends(a, nd, tile, smem);
+  else if constexpr (K == K_RLE_EXPAND) body_rle_expand<ES>(a, nd, tile, smem);
+  else if constexpr (K == K_RLE_EXPAND_BOOL) body_rle_expand_bool(a, nd, tile, smem);
+  else if constexpr (K == K_SPARSE_BITS) body_sparse_bits(a, nd, tile, smem);
+  else if constexpr (K == K_SELECT_SCATTER) body_select_scatter<ES>(a, nd, tile, smem);
+  else if constexpr (K == K_SELECT_BITS) body_select_bits(a, nd, tile, smem);
+  else if constexpr (K == K_DICT_GATHER) body_dict_gather<ES>(a, nd, tile, smem);
+  else if constexpr (K == K_VARINT_DECODE) body_varint_decode<(ES == 4 ? 4 : 8)>(a, nd, tile, smem);
+  else if constexpr (K == K_STRING_VIEWS) body_string_views(a, nd, tile, smem);
+  else if constexpr (K == K_COPY_BYTES) body_copy_bytes(a, nd, tile, smem);
+}
+
+// One kernel per operation (used when the plan is not fused: profiling, tuning).
+template <uint32_t OP>
+__device__ __forceinline__ void single_op_kernel(const KArgs& a) {
+  __shared__ __align__(16) uint8_t smem[kSmemBytes];
+  const TileRef tr = a.tiles[blockIdx.x];
+  run_op<OP>(a, a.nodes[tr.node], tr.tile & kTileMask, smem);
+}
+#define NBL_KERNEL_ES(name, KID) \
+  template <int ES> __global__ __launch_bounds__(256) void name(KArgs a) { single_op_kernel<make_op(KID, ES)>(a); }
+#define NBL_KERNEL(name, KID) \
+  __global__ __launch_bounds__(256) void name(KArgs a) { single_op_kernel<make_op(KID, 1)>(a); }
+NBL_KERNEL_ES(k_materialize, K_MATERIALIZE)
+NBL_KERNEL_ES(k_materialize_fbw, K_MATERIALIZE_FBW)
+NBL_KERNEL_ES(k_materialize_raw, K_MATERIALIZE_RAW)
+NBL_KERNEL(k_bits_to_bytes, K_BITS_TO_BYTES)
+NBL_KERNEL(k_reduce_sum, K_REDUCE_SUM)
+NBL_KERNEL(k_reduce_popc, K_REDUCE_POPC)
+NBL_KERNEL(k_reduce_varint, K_REDUCE_VARINT)
+NBL_KERNEL(k_scan_tiles, K_SCAN_TILES)
+NBL_KERNEL(k_rle_ends, K_RLE_ENDS)
+NBL_KERNEL_ES(k_rle_expand, K_RLE_EXPAND)
+NBL_KERNEL(k_rle_expand_bool, K_RLE_EXPAND_BOOL)
+NBL_KERNEL(k_sparse_bits, K_SPARSE_BITS)
+NBL_KERNEL_ES(k_select_scatter, K_SELECT_SCATTER)
+NBL_KERNEL(k_select_bits, K_SELECT_BITS)
+NBL_KERNEL_ES(k_dict_gather, K_DICT_GATHER)
+NBL_KERNEL_ES(k_varint_decode, K_VARINT_DECODE)
+NBL_KERNEL(k_string_views, K_STRING_VIEWS)
+NBL_KERNEL(k_copy_bytes, K_COPY_BYTES)
+#undef NBL_KERNEL_ES
+#undef NBL_KERNEL
+
+// The fused launch: one grid runs every step of one cascade level of the whole
+// batch; each workgroup reads its operation from its tile entry (workgroup
+// uniform, so the switch costs one scalar branch).  LAST only changes the
+// kernel's name, so that profiles tell the output-writing level from the
+// preparatory ones.
+template <bool LAST>
+__global__ __launch_bounds__(256, 8) void k_level(KArgs a) {
+  __shared__ __align__(16) uint8_t smem[kSmemBytes];
+  const TileRef tr = a.tiles[blockIdx.x];
+  const NodeDesc& nd = a.nodes[tr.node];
+  const uint32_t tile = tr.tile & kTileMask;
+#define NBL_OP(KID, ES) case make_op(KID, ES): run_op<make_op(KID, ES)>(a, nd, tile, smem); break;
+#define NBL_OP_ALL_ES(KID) NBL_OP(KID, 1) NBL_OP(KID, 2) NBL_OP(KID, 4) NBL_OP(KID, 8)
+  switch (tr.tile >> kOpShift) {
+    NBL_OP_ALL_ES(K_MATERIALIZE)
+    NBL_OP_ALL_ES(K_MATERIALIZE_FBW)
+    NBL_OP_ALL_ES(K_MATERIALIZE_RAW)
+    NBL_OP(K_BITS_TO_BYTES, 1)
+    NBL_OP(K_REDUCE_SUM, 1)
+    NBL_OP(K_REDUCE_POPC, 1)
+    NBL_OP(K_REDUCE_VARINT, 1)
+    NBL_OP(K_SCAN_TILES, 1)
+    NBL_OP(K_RLE_ENDS, 1)
+    NBL_OP_ALL_ES(K_RLE_EXPAND)
+    NBL_OP(K_RLE_EXPAND_BOOL, 1)
+    NBL_OP(K_SPARSE_BITS, 1)
+    NBL_OP_ALL_ES(K_SELECT_SCATTER)
+    NBL_OP(K_SELECT_BITS, 1)
+    NBL_OP_ALL_ES(K_DICT_GATHER)
+    NBL_OP(K_VARINT_DECODE, 4)
+    NBL_OP(K_VARINT_DECODE, 8)
+    NBL_OP(K_STRING_VIEWS, 1)
+    NBL_OP(K_COPY_BYTES, 1)
+    default: break;
+  }
+#undef NBL_OP_ALL_ES
+#undef NBL_OP
 }
 
 }  // namespace nbl
 
 // ------------------------------------------------------------------ launcher
+// `kernel` is a KernelId, or K_LEVEL / K_LEVEL_LAST for a fused launch (then
+// `es` is ignored).  Kernels whose body does not depend on the element size
+// take any `es`.
 extern "C" int nbl_launch_kernel(uint32_t kernel, uint32_t es, const nbl::KArgs* args, void* stream) {
   using namespace nbl;
   const KArgs a = *args;
@@ -949,6 +1386,8 @@ extern "C" int nbl_launch_kernel(uint32_t kernel, uint32_t es, const nbl::KArgs*
     default: return -1;                                                               \
   }
   switch (kernel) {
+    case K_LEVEL: hipLaunchKernelGGL(k_level<false>, grid, block, 0, s, a); break;
+    case K_LEVEL_LAST: hipLaunchKernelGGL(k_level<true>, grid, block, 0, s, a); break;
     case K_MATERIALIZE: NBL_BY_ES(k_materialize); break;
     case K_MATERIALIZE_FBW: NBL_BY_ES(k_materialize_fbw); break;
     case K_MATERIALIZE_RAW: NBL_BY_ES(k_materialize_raw); break;

@@ -96,13 +96,15 @@ struct Step {
   uint32_t n_tiles;
   bool per_node;  // K_SCAN_TILES: one workgroup, tile index unused
   int chunk;      // >= 0 when this step writes the final values of that chunk
+  int owner;      // chunk the step belongs to
 };
 
 struct Launch {
-  uint32_t kernel, es;
+  uint32_t kernel, es;  // KernelId, or K_LEVEL / K_LEVEL_LAST for a fused launch
   uint32_t tile_begin, n_tiles;
   int level;
   uint64_t alg_bytes;
+  std::string name;     // as a profiler shows it, e.g. "k_materialize_fbw<8>", "k_level<true>"
 };
 
 const char* kKernelNames[K_COUNT] = {
@@ -128,6 +130,8 @@ struct nbl_plan {
   std::vector<Step> steps;
   std::vector<Launch> launches;
   std::vector<TileRef> tiles;
+  bool fused = true;          // one launch per cascade level (default) or one per (level, kernel, element size)
+  int cur_chunk = -1;         // chunk being planned
   std::vector<uint8_t> blob;  // NodeDesc[] | TileRef[] image uploaded to work
   uint64_t tiles_off = 0;
   uint64_t ctrl_off = 0, ctrl_bytes = 0;   // status word + per-node totals (zeroed per decode)
@@ -157,7 +161,8 @@ struct nbl_plan {
   }
   void add_step(int level, uint32_t kernel, uint32_t es, uint32_t dnode, uint32_t n_tiles, bool per_node = false) {
     if (n_tiles == 0) return;
-    steps.push_back(Step{level, kernel, es, dnode, n_tiles, per_node, -1});
+    if (n_tiles > kTileMask) fail(NBL_ERR_UNSUPPORTED, "a node of %u tiles exceeds the tile table's range", n_tiles);
+    steps.push_back(Step{level, kernel, es, dnode, n_tiles, per_node, -1, cur_chunk});
   }
   void alloc_scan(NodeDesc& d, uint32_t n_tiles) {
     d.part_base = n_parts; d.n_parts = n_tiles; n_parts += n_tiles;
@@ -181,6 +186,15 @@ int elem_size(uint8_t dt) {
   }
 }
 bool is_u32_index_type(uint8_t dt) { return dt == DT_UINT32 || dt == DT_INT32; }
+
+// Which materialise variant unpacks the leaf column `ref` of `es`-byte elements.
+uint32_t leaf_kernel(const ColRef& ref, uint32_t es) {
+  const uint32_t w = ref.width;
+  const bool window = w >= 1 && (es == 8 ? w <= 63 : es == 4 ? w <= 31 : es == 2 ? w <= 15 : w <= 7);
+  if (ref.kind == COL_RAW || (ref.kind == COL_FBW && w == 8 * es)) return K_MATERIALIZE_RAW;
+  if (ref.kind == COL_FBW && window) return K_MATERIALIZE_FBW;
+  return K_MATERIALIZE;
+}
 
 }  // namespace
 
@@ -530,6 +544,23 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       d.self = mat_ref(es);
       d.c0 = C(1).ref;  // indices
       d.c1 = C(0).ref;  // alphabet
+      {
+        // the gather reads the alphabet as a plain element array: anything else
+        // (bit-packed, constant) is unpacked into work first -- alphabets are small
+        const ColRef& ar = d.c1;
+        const bool plain = ar.kind == COL_RAW || ar.kind == COL_MAT_WORK || ar.kind == COL_MAT_OUT ||
+                           (ar.kind == COL_FBW && ar.width == 8 * es);
+        if (!plain && C(0).rows > 0) {
+          NodeDesc m{};
+          m.self.kind = COL_MAT_WORK; m.self.off = alloc_work((uint64_t)C(0).rows * es);
+          m.self.rows = C(0).rows; m.self.es = (uint8_t)es;
+          m.c0 = ar; m.rows = C(0).rows;
+          const uint32_t mn = add_dnode(m);
+          add_step(C(0).ready, leaf_kernel(ar, es), es, mn, div_up32(C(0).rows, tile_rows));
+          d.c1 = m.self;
+          lvl = std::max(lvl, C(0).ready + 1);
+        }
+      }
       d.rows = rows;
       const uint32_t dn = add_dnode(d);
       add_step(lvl, K_DICT_GATHER, es, dn, div_up32(rows, tile_rows));
@@ -588,12 +619,7 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       d.self = *root_dst; d.self.rows = rows; d.self.es = (uint8_t)es;
       d.c0 = r.ref; d.rows = rows;
       const uint32_t dn = add_dnode(d);
-      uint32_t kernel = K_MATERIALIZE;
-      const uint32_t w = r.ref.width;
-      const bool window = w >= 1 && (es == 8 ? w <= 63 : es == 4 ? w <= 31 : es == 2 ? w <= 15 : w <= 7);
-      if (r.ref.kind == COL_RAW || (r.ref.kind == COL_FBW && w == 8 * es)) kernel = K_MATERIALIZE_RAW;
-      else if (r.ref.kind == COL_FBW && window) kernel = K_MATERIALIZE_FBW;
-      add_step(r.ready, kernel, es, dn, div_up32(rows, tile_rows));
+      add_step(r.ready, leaf_kernel(r.ref, es), es, dn, div_up32(rows, tile_rows));
       r.ready += 1;
     }
   }
@@ -601,6 +627,7 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
 
 void nbl_plan::plan_chunk(uint32_t c, uint64_t off, uint64_t size) {
   chunk_copies.clear();
+  cur_chunk = (int)c;
   const int root = parse(off, size, (int)c, 0);
   roots.push_back(root);
   const PNode r = nodes[root];
@@ -640,23 +667,47 @@ void nbl_plan::plan_chunk(uint32_t c, uint64_t off, uint64_t size) {
   total_rows += r.rows;
 }
 
-// Orders the steps by level, merges equal (level, kernel, element size) into one
-// launch and lays out the work buffer.
+// Schedules the steps and lays out the work buffer.
+//
+// Levels: a step's level is its dependency depth inside its chunk.  Every
+// chunk is then shifted as late as possible, so that the steps writing final
+// outputs of ALL chunks share the last level: the preparatory levels hold only
+// the small scan / run-end / bitmap steps of the deeper cascades, and the last
+// one is a single large launch that mixes bandwidth-bound tiles (unpack, copy)
+// with latency-bound ones (run expansion, rank scatter).
+// Launches: fused (default) = one launch per level, tiles sorted by operation;
+// otherwise one launch per (level, kernel, element size).
 void nbl_plan::finish() {
+  int last_level = 0;
+  std::vector<int> chunk_last(layouts.size(), 0);
+  for (const Step& st : steps) {
+    last_level = std::max(last_level, st.level);
+    if (st.owner >= 0) chunk_last[(size_t)st.owner] = std::max(chunk_last[(size_t)st.owner], st.level);
+  }
+  for (Step& st : steps)
+    if (st.owner >= 0) st.level += last_level - chunk_last[(size_t)st.owner];
   std::stable_sort(steps.begin(), steps.end(), [](const Step& a, const Step& b) {
     return std::tie(a.level, a.kernel, a.es) < std::tie(b.level, b.kernel, b.es);
   });
   for (size_t i = 0; i < steps.size();) {
     size_t j = i;
-    Launch L{steps[i].kernel, steps[i].es, (uint32_t)tiles.size(), 0, steps[i].level, 0};
-    while (j < steps.size() && steps[j].level == steps[i].level && steps[j].kernel == steps[i].kernel && steps[j].es == steps[i].es) {
-      for (uint32_t t = 0; t < steps[j].n_tiles; ++t) tiles.push_back(TileRef{steps[j].dnode, t});
-      if (steps[j].chunk >= 0) {
-        L.alg_bytes += chunk_alg[(size_t)steps[j].chunk];
-      }
+    Launch L{steps[i].kernel, steps[i].es, (uint32_t)tiles.size(), 0, steps[i].level, 0, std::string()};
+    while (j < steps.size() && steps[j].level == steps[i].level &&
+           (fused || (steps[j].kernel == steps[i].kernel && steps[j].es == steps[i].es))) {
+      const uint32_t op = op_of(steps[j].kernel, steps[j].es) << kOpShift;
+      for (uint32_t t = 0; t < steps[j].n_tiles; ++t) tiles.push_back(TileRef{steps[j].dnode, op | t});
+      if (steps[j].chunk >= 0) L.alg_bytes += chunk_alg[(size_t)steps[j].chunk];
       ++j;
     }
     L.n_tiles = (uint32_t)tiles.size() - L.tile_begin;
+    if (fused) {
+      L.kernel = L.level == last_level ? K_LEVEL_LAST : K_LEVEL;
+      L.es = 0;
+      L.name = L.kernel == K_LEVEL_LAST ? "k_level<true>" : "k_level<false>";
+    } else {
+      L.name = kKernelNames[L.kernel];
+      if (kernel_has_es(L.kernel)) L.name += "<" + std::to_string(L.es) + ">";
+    }
     launches.push_back(L);
     i = j;
   }
@@ -716,7 +767,8 @@ nbl_status nbl_plan_batch(const uint8_t* base, const uint64_t* offsets, const ui
   nbl_plan* p = new nbl_plan();
   try {
     p->base = base;
-    p->varint_rows = options && options->struct_size >= sizeof(nbl_options) && options->use_varint_row_count;
+    p->varint_rows = options && options->struct_size >= 8 && options->use_varint_row_count;
+    p->fused = !(options && options->struct_size >= 12 && (options->flags & NBL_PLAN_PER_KERNEL_LAUNCHES));
     p->layouts.resize(n_chunks);
     for (uint32_t c = 0; c < n_chunks; ++c) p->span = std::max(p->span, offsets[c] + sizes[c]);
     for (uint32_t c = 0; c < n_chunks; ++c) p->plan_chunk(c, offsets[c], sizes[c]);
@@ -763,7 +815,7 @@ nbl_status nbl_plan_get_chunk_layout(const nbl_plan* p, uint32_t chunk, nbl_chun
 nbl_status nbl_plan_get_launch(const nbl_plan* p, uint32_t launch, nbl_launch_info* info) {
   if (!p || !info || launch >= p->launches.size()) { g_last_error = "bad launch index"; return NBL_ERR_ARGUMENT; }
   const Launch& L = p->launches[launch];
-  info->kernel = kKernelNames[L.kernel];
+  info->kernel = L.name.c_str();
   info->elem_bytes = L.es;
   info->n_tiles = L.n_tiles;
   info->level = (uint32_t)L.level;
@@ -850,6 +902,10 @@ nbl_status nbl_profile_collect(nbl_profile* pr, float* mean_ms, uint32_t n_launc
 static nbl_status decode_impl(const nbl_plan* p, nbl_profile* prof, uint32_t step, const void* d_arena, void* d_out,
                               void* d_work, void* stream) {
   if (!p || !d_work || (!d_arena && p->span) || !d_out) { g_last_error = "null argument"; return NBL_ERR_ARGUMENT; }
+  if ((reinterpret_cast<uintptr_t>(d_arena) | reinterpret_cast<uintptr_t>(d_out) | reinterpret_cast<uintptr_t>(d_work)) & 15u) {
+    g_last_error = "d_arena, d_out and d_work must be 16-byte aligned";
+    return NBL_ERR_ARGUMENT;
+  }
   uint8_t* work = static_cast<uint8_t*>(d_work);
   hipError_t e = hipMemsetAsync(work + p->ctrl_off, 0, p->ctrl_bytes, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return hip_fail("hipMemsetAsync(control words)", e);
@@ -871,7 +927,7 @@ static nbl_status decode_impl(const nbl_plan* p, nbl_profile* prof, uint32_t ste
     const int rc = nbl_launch_kernel(L.kernel, L.es, &a, stream);
     if (prof) (void)hipEventRecord(prof->events[((size_t)step * nl + li) * 2 + 1], static_cast<hipStream_t>(stream));
     if (rc != 0) {
-      g_last_error = std::string("launch of ") + kKernelNames[L.kernel] + " failed";
+      g_last_error = "launch of " + L.name + " failed";
       return NBL_ERR_HIP;
     }
   }

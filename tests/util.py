@@ -156,6 +156,11 @@ def check_parity(O, encodings, varint_rows: bool = False, labels=None):
 
     results = decode_encodings(encodings, varint_rows)
     assert len(results) == len(encodings)
+    # the same batch with one launch per operation instead of one per level
+    unfused = decode_encodings(encodings, varint_rows, per_kernel=True)
     for i, (enc, res) in enumerate(zip(encodings, results)):
-        assert_chunk_equal(res, oracle_chunk(O, enc, varint_rows), labels[i] if labels else f"chunk {i}")
+        label = labels[i] if labels else f"chunk {i}"
+        ora = oracle_chunk(O, enc, varint_rows)
+        assert_chunk_equal(res, ora, label)
+        assert_chunk_equal(unfused[i], ora, label + " (per-operation launches)")
     return results

@@ -25,10 +25,10 @@ def per_kernel(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        m = re.search(r"nbl::(k_\w+)(?:<(\d+)>)?", r["Kernel_Name"])
+        m = re.search(r"nbl::(k_\w+(?:<\w+>)?)", r["Kernel_Name"])
         if not m:
             continue
-        agg[f"{m.group(1)}<{m.group(2) or 0}>"].append(float(r["Counter_Value"]))
+        agg[m.group(1)].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
 
 

@@ -35,7 +35,7 @@ for dtype, widths in ((W.INT32, (1, 3, 7, 8, 13, 16, 24, 32)), (W.INT64, (1, 3, 
         blob = (enc + bytes(pad)) if misalign == 0 else (enc + bytes(pad + misalign))
         buf = np.frombuffer(blob * k, dtype=np.uint8)
         offs = [(i * len(blob), len(enc)) for i in range(k)]
-        plan = Plan(buf, offs)
+        plan = Plan(buf, offs, per_kernel=True)
         dec = BatchDecoder(plan)
         dec.stage()
         for _ in range(3):
