@@ -97,6 +97,9 @@ struct Step {
   bool per_node;  // K_SCAN_TILES: one workgroup, tile index unused
   int chunk;      // >= 0 when this step writes the final values of that chunk
   int owner;      // chunk the step belongs to
+  uint32_t tile_begin = 0;  // first tile of the node this step covers (steps can be split)
+  uint64_t alg = 0;         // algorithmic bytes credited to this step (set by finish())
+  bool filler = false;      // a free step placed in a level to fill it: its tiles go after the level's own
 };
 
 struct Launch {
@@ -162,7 +165,7 @@ struct nbl_plan {
   void add_step(int level, uint32_t kernel, uint32_t es, uint32_t dnode, uint32_t n_tiles, bool per_node = false) {
     if (n_tiles == 0) return;
     if (n_tiles > kTileMask) fail(NBL_ERR_UNSUPPORTED, "a node of %u tiles exceeds the tile table's range", n_tiles);
-    steps.push_back(Step{level, kernel, es, dnode, n_tiles, per_node, -1, cur_chunk});
+    steps.push_back(Step{level, kernel, es, dnode, n_tiles, per_node, -1, cur_chunk, 0, 0});
   }
   void alloc_scan(NodeDesc& d, uint32_t n_tiles) {
     d.part_base = n_parts; d.n_parts = n_tiles; n_parts += n_tiles;
@@ -171,6 +174,7 @@ struct nbl_plan {
   uint64_t string_copy(int level, uint64_t arena_off, uint64_t bytes);
   void place(int idx, bool root, const ColRef* root_dst);
   void plan_chunk(uint32_t c, uint64_t off, uint64_t size);
+  void spread_free_steps(int last_level);
   void finish();
 };
 
@@ -594,7 +598,7 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       alloc_scan(d, nt);
       d.self = nn.is_bool ? bits_ref() : mat_ref(es);
       const uint32_t dn = add_dnode(d);
-      add_step(lvl, K_REDUCE_POPC, 0, dn, nt);
+      add_step(lvl, K_REDUCE_POPC, 0, dn, div_up32(rows, kBitTileRows));  // each tile emits the partials of kBitTileRows / trows consumer tiles
       add_step(lvl + 1, K_SCAN_TILES, 0, dn, 1, true);
       if (nn.is_bool) add_step(lvl + 2, K_SELECT_BITS, 0, dn, nt);
       else add_step(lvl + 2, K_SELECT_SCATTER, es, dn, nt);
@@ -667,6 +671,63 @@ void nbl_plan::plan_chunk(uint32_t c, uint64_t off, uint64_t size) {
   total_rows += r.rows;
 }
 
+// A step is free when nothing on the device depends on it and it depends on
+// nothing: the single unpack / copy / fill of a leaf-only chunk, and the string
+// blob copies.  Such steps need not wait for the last level.  They are cut into
+// tile ranges and dealt out over ALL levels so that every level carries about
+// the same number of tiles: the preparatory steps of deep cascades (tile sums,
+// scans, run ends -- a few hundred small, latency-bound tiles per level) then
+// run underneath bandwidth-bound work instead of holding the GPU on their own.
+void nbl_plan::spread_free_steps(int last_level) {
+  const size_t n_levels = (size_t)last_level + 1;
+  std::vector<uint32_t> steps_of_chunk(layouts.size(), 0);
+  for (const Step& st : steps)
+    if (st.owner >= 0) ++steps_of_chunk[(size_t)st.owner];
+  std::vector<uint64_t> fixed(n_levels, 0);
+  std::vector<size_t> free_steps;
+  uint64_t free_tiles = 0, all_tiles = 0;
+  for (size_t i = 0; i < steps.size(); ++i) {
+    const Step& st = steps[i];
+    const bool is_free = st.kernel == K_COPY_BYTES || (st.owner >= 0 && steps_of_chunk[(size_t)st.owner] == 1);
+    all_tiles += st.n_tiles;
+    if (is_free) { free_steps.push_back(i); free_tiles += st.n_tiles; }
+    else fixed[(size_t)st.level] += st.n_tiles;
+  }
+  if (free_tiles == 0) return;
+  // level l takes free tiles up to the common target; what does not fit goes to the last level
+  const uint64_t target = (all_tiles + n_levels - 1) / n_levels;
+  std::vector<uint64_t> room(n_levels, 0);
+  for (size_t l = 0; l < n_levels; ++l) room[l] = target > fixed[l] ? target - fixed[l] : 0;
+  size_t level = 0;
+  std::vector<Step> pieces;
+  for (size_t i : free_steps) {
+    Step st = steps[i];
+    const uint64_t whole_alg = st.alg;
+    const uint32_t whole_tiles = st.n_tiles;
+    uint32_t done = 0;
+    uint64_t alg_done = 0;
+    bool first = true;
+    while (done < whole_tiles) {
+      while (level + 1 < n_levels && room[level] == 0) ++level;
+      uint32_t take = whole_tiles - done;
+      if (level + 1 < n_levels && take > room[level]) take = (uint32_t)room[level];
+      Step piece = st;
+      piece.filler = true;
+      piece.level = (int)level;
+      piece.tile_begin = st.tile_begin + done;
+      piece.n_tiles = take;
+      done += take;
+      // bytes in proportion to tiles; the last piece takes the remainder so the sum stays exact
+      piece.alg = done == whole_tiles ? whole_alg - alg_done : whole_alg * take / whole_tiles;
+      alg_done += piece.alg;
+      if (level + 1 < n_levels) room[level] -= take;
+      if (first) { steps[i] = piece; first = false; }
+      else pieces.push_back(piece);
+    }
+  }
+  steps.insert(steps.end(), pieces.begin(), pieces.end());
+}
+
 // Schedules the steps and lays out the work buffer.
 //
 // Levels: a step's level is its dependency depth inside its chunk.  Every
@@ -686,8 +747,11 @@ void nbl_plan::finish() {
   }
   for (Step& st : steps)
     if (st.owner >= 0) st.level += last_level - chunk_last[(size_t)st.owner];
+  for (Step& st : steps)
+    if (st.chunk >= 0) st.alg = chunk_alg[(size_t)st.chunk];
+  if (fused && last_level > 0) spread_free_steps(last_level);
   std::stable_sort(steps.begin(), steps.end(), [](const Step& a, const Step& b) {
-    return std::tie(a.level, a.kernel, a.es) < std::tie(b.level, b.kernel, b.es);
+    return std::tie(a.level, a.filler, a.kernel, a.es) < std::tie(b.level, b.filler, b.kernel, b.es);
   });
   for (size_t i = 0; i < steps.size();) {
     size_t j = i;
@@ -695,8 +759,8 @@ void nbl_plan::finish() {
     while (j < steps.size() && steps[j].level == steps[i].level &&
            (fused || (steps[j].kernel == steps[i].kernel && steps[j].es == steps[i].es))) {
       const uint32_t op = op_of(steps[j].kernel, steps[j].es) << kOpShift;
-      for (uint32_t t = 0; t < steps[j].n_tiles; ++t) tiles.push_back(TileRef{steps[j].dnode, op | t});
-      if (steps[j].chunk >= 0) L.alg_bytes += chunk_alg[(size_t)steps[j].chunk];
+      for (uint32_t t = 0; t < steps[j].n_tiles; ++t) tiles.push_back(TileRef{steps[j].dnode, op | (steps[j].tile_begin + t)});
+      L.alg_bytes += steps[j].alg;
       ++j;
     }
     L.n_tiles = (uint32_t)tiles.size() - L.tile_begin;
