@@ -11,7 +11,7 @@ Corrections applied (MI355X / gfx950):
     script prints fetch*2/write for it, which must be close to 1;
   * WRITE_SIZE is exact for 16-byte-per-lane streaming stores.
 
-usage: pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv out.json [rows]
+usage: pmc_traffic.py FETCH_counter_collection.csv WRITE_counter_collection.csv out.json [rows] [workload]
 """
 import collections
 import csv
@@ -36,7 +36,8 @@ def main():
     fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     rows = int(sys.argv[4]) if len(sys.argv) > 4 else 10_000_000
-    out = {"rows": rows, "unit": "bytes per launch", "fetch_correction": 2.0, "kernels": {}}
+    workload = sys.argv[5] if len(sys.argv) > 5 else "fbw_rle"
+    out = {"workload": workload, "rows": rows, "unit": "bytes per launch", "fetch_correction": 2.0, "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         f = fetch.get(k, (0.0, 0))
         w = write.get(k, (0.0, 0))
@@ -45,7 +46,7 @@ def main():
         out["kernels"][k] = {"read_bytes": round(rd), "write_bytes": round(wr), "traffic_bytes": round(rd + wr),
                              "launches_sampled": min(f[1], w[1])}
     for k, v in out["kernels"].items():
-        if k.startswith("k_materialize_raw") and v["write_bytes"]:
+        if k.startswith("k_materialize_raw") and v["write_bytes"]:  # present in per-operation (unfused) runs
             v["calibration_read_over_write"] = round(v["read_bytes"] / v["write_bytes"], 4)
             print(f"calibration {k}: corrected read / write = {v['calibration_read_over_write']}")
     json.dump(out, open(sys.argv[3], "w"), indent=1)
