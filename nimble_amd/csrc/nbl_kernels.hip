@@ -978,12 +978,13 @@ template <int ES>
 __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
   using T = typename ElemT<ES>::type;
   constexpr uint32_t V = 16 / ES;
-  constexpr uint32_t TE = kTileBytes / ES;
+  constexpr uint32_t TE = select_tile_rows(ES);
   constexpr uint32_t W = TE / 64;
-  constexpr uint32_t B = kBatch<ES>;
-  uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem);             // W <= 256 words
-  uint32_t* s_pref = reinterpret_cast<uint32_t*>(smem + 2048);       // W words
-  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + 3072);
+  static_assert(TE * ES == kTileBytes && W <= kBlock, "tile geometry");
+  T* s_vals = reinterpret_cast<T*>(smem);                                   // the tile's selected values, <= TE
+  uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem + kTileBytes);         // W <= 256 words
+  uint32_t* s_pref = reinterpret_cast<uint32_t*>(smem + kTileBytes + 2048);  // W words
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + kTileBytes + 3072);
   const uint64_t rows = nd.rows;
   const uint64_t p0 = (uint64_t)tile * TE;
   const uint32_t tile_rows = rows - p0 < TE ? (uint32_t)(rows - p0) : TE;
@@ -991,57 +992,83 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
   T* dst = reinterpret_cast<T*>(self_ptr(nd, a)) + p0;
   const uint32_t nvals = nd.c1.rows;
   if (tile == 0 && threadIdx.x == 0 && a.totals[nd.total_idx] != nvals) atomicOr(a.status, ST_SELECT_COUNT);
+  // The tile's selected rows take the consecutive ranks [base, next): both come
+  // from the scanned partials, so the values are requested at once, without
+  // waiting for the bitmap.  They are copied to LDS with coalesced loads (each
+  // fetched once); every row then picks its value -- or the fill -- from LDS.
+  // Counts that disagree with the values child (corrupt input) are clamped.
+  const uint32_t base = a.parts[nd.part_base + tile];
+  const uint32_t next = tile + 1 < nd.n_parts ? a.parts[nd.part_base + tile + 1] : a.totals[nd.total_idx];
+  const uint32_t count = next - base < TE ? next - base : TE;
+  const uint32_t avail = base < nvals ? nvals - base : 0u;
+  const uint32_t n = count < avail ? count : avail;
   const uint64_t w = (uint64_t)tile * W + threadIdx.x;
   uint64_t word = 0;
-  if (threadIdx.x < W && w * 64 < rows) {
-    word = bits_word_masked(nd.sel, a, w, invert);
-    if (nd.flags & NF_WRITE_NULLS) reinterpret_cast<uint64_t*>(a.out + nd.aux_off)[w] = invert ? bits_word_masked(nd.sel, a, w, false) : word;
+  if (threadIdx.x < W && w * 64 < rows) word = bits_word_masked(nd.sel, a, w, invert);
+  constexpr bool kStage = ES < 8;  // 8-byte rows: two values per lane and round, cheaper fetched directly (below)
+  if (kStage && n) {
+    with_reader<ES>(nd.c1, a, [&](auto rd) {
+      const auto vals = rd.view(base);
+      for (uint32_t j0 = threadIdx.x; j0 < n; j0 += 8 * kBlock) {  // eight loads in flight per thread
+        T t[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+          const uint32_t j = j0 + u * kBlock;
+          t[u] = vals.at(j < n ? j : n - 1);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+          const uint32_t j = j0 + u * kBlock;
+          if (j < n) s_vals[j] = t[u];
+        }
+      }
+    });
   }
+  if ((nd.flags & NF_WRITE_NULLS) && threadIdx.x < W && w * 64 < rows)
+    reinterpret_cast<uint64_t*>(a.out + nd.aux_off)[w] = invert ? ~word & (w * 64 + 64 > rows ? wmask((uint32_t)(rows - w * 64)) : ~0ull) : word;
   uint32_t total;
   const uint32_t ex = block_excl_scan((uint32_t)__popcll(word), tmp, total);
   if (threadIdx.x < W) { s_bits[threadIdx.x] = word; s_pref[threadIdx.x] = ex; }
   __syncthreads();
-  const uint32_t base = a.parts[nd.part_base + tile];
   const T fill = (T)nd.aux;
-  if (nvals == 0) {
-#pragma unroll
-    for (uint32_t it = 0; it < 4; ++it) {
-      const uint32_t q0 = (it * kBlock + threadIdx.x) * V;
-      if (q0 >= tile_rows) break;
+  const uint32_t last = n ? n - 1 : 0u;
+  if constexpr (!kStage) {
+    if (n == 0) {
       Vec16<ES> x;
 #pragma unroll
       for (uint32_t j = 0; j < V; ++j) x.v[j] = fill;
-      store_vec<ES>(dst, q0, tile_rows, x);
+#pragma unroll
+      for (uint32_t it = 0; it < 4; ++it) {
+        const uint32_t q0 = (it * kBlock + threadIdx.x) * V;
+        if (q0 < tile_rows) store_vec<ES>(dst, q0, tile_rows, x);
+      }
+      return;
     }
-    return;
-  }
-  // values of this tile start at rank `first`; a lane's rank is first + rel,
-  // rel <= TE, clamped to the last value (corrupt counts cannot run past it)
-  const uint32_t first = base < nvals ? base : nvals - 1;
-  const uint32_t last_rel = nvals - 1 - first;
-  with_reader<ES>(nd.c1, a, [&](auto rd) {
-    const auto vals = rd.view(first);
+    // Selected rows take consecutive ranks, so these per-lane loads are lane
+    // monotone (coalesced).  They are issued unconditionally at a clamped rank
+    // -- a lane whose bit is clear loads its successor's value and drops it --
+    // which keeps all eight loads of the tile in flight at once.
+    with_reader<ES>(nd.c1, a, [&](auto rd) {
+      const auto vals = rd.view(base);
+      T x[4][V];
+      uint32_t bv[4];
 #pragma unroll
-    for (uint32_t ib = 0; ib < 4; ib += B) {
-      T x[B][V];
-      uint32_t bv[B];
-#pragma unroll
-      for (uint32_t u = 0; u < B; ++u) {
-        const uint32_t q0 = ((ib + u) * kBlock + threadIdx.x) * V;
+      for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t q0 = (u * kBlock + threadIdx.x) * V;
         const uint64_t wd = s_bits[q0 >> 6];
         const uint32_t b = q0 & 63;
         uint32_t r = s_pref[q0 >> 6] + (uint32_t)__popcll(wd & ((1ull << b) - 1ull));
-        const uint32_t bits = (uint32_t)(wd >> b);  // bit j = row q0 + j (b + V <= 64)
+        const uint32_t bits = (uint32_t)(wd >> b);
         bv[u] = bits;
 #pragma unroll
         for (uint32_t j = 0; j < V; ++j) {
-          x[u][j] = vals.at(r < last_rel ? r : last_rel);
+          x[u][j] = vals.at(r < last ? r : last);
           r += (bits >> j) & 1u;
         }
       }
 #pragma unroll
-      for (uint32_t u = 0; u < B; ++u) {
-        const uint32_t q0 = ((ib + u) * kBlock + threadIdx.x) * V;
+      for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t q0 = (u * kBlock + threadIdx.x) * V;
         if (q0 < tile_rows) {
           Vec16<ES> o;
 #pragma unroll
@@ -1049,8 +1076,27 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
           store_vec<ES>(dst, q0, tile_rows, o);
         }
       }
+    });
+    return;
+  }
+#pragma unroll
+  for (uint32_t it = 0; it < 4; ++it) {
+    const uint32_t q0 = (it * kBlock + threadIdx.x) * V;
+    if (q0 >= tile_rows) break;
+    const uint64_t wd = s_bits[q0 >> 6];
+    const uint32_t b = q0 & 63;
+    uint32_t r = s_pref[q0 >> 6] + (uint32_t)__popcll(wd & ((1ull << b) - 1ull));
+    const uint32_t bits = n ? (uint32_t)(wd >> b) : 0u;  // bit j = row q0 + j (b + V <= 64)
+    Vec16<ES> o;
+    o.q = make_u32x4(0, 0, 0, 0);
+#pragma unroll
+    for (uint32_t j = 0; j < V; ++j) {
+      const T v = s_vals[r < last ? r : last];
+      vec_set<ES>(o, j, ((bits >> j) & 1u) ? v : fill);
+      r += (bits >> j) & 1u;
     }
-  });
+    store_vec<ES>(dst, q0, tile_rows, o);
+  }
 }
 
 // Nullable<bool>: scatter a bitmap of values by the selection bitmap.

@@ -592,7 +592,7 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
         d.flags |= NF_WRITE_NULLS;
         d.aux_off = layouts[(size_t)nn.chunk].nulls_offset;
       }
-      const uint32_t trows = nn.is_bool ? kBitTileRows : tile_rows;
+      const uint32_t trows = nn.is_bool ? kBitTileRows : select_tile_rows(es);
       d.aux2 = trows;
       const uint32_t nt = div_up32(rows, trows);
       alloc_scan(d, nt);

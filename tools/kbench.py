@@ -53,6 +53,11 @@ CASES = {
     "nullable/i32/5%/fbw+sparse": lambda: nullable(W.INT32, np.uint32, 0.05, E.FixedBitWidth(), E.SparseBool()),
     "nullable/f32/99%/trivial+sparse": lambda: nullable(W.FLOAT, np.uint32, 0.99, E.Trivial(), E.SparseBool()),
     "nullable/f32/20%/trivial+bitmap": lambda: nullable(W.FLOAT, np.uint32, 0.2, E.Trivial(), E.Trivial()),
+    "small/nullable/f32/99%/100K": lambda: nullable(W.FLOAT, np.uint32, 0.99, E.Trivial(), E.SparseBool(), n=100_000),
+    "small/nullable/f32/80%/100K": lambda: nullable(W.FLOAT, np.uint32, 0.80, E.Trivial(), E.SparseBool(), n=100_000),
+    "small/nullable/f32/20%/100K": lambda: nullable(W.FLOAT, np.uint32, 0.20, E.Trivial(), E.Trivial(), n=100_000),
+    "small/fbw/i32/w13/100K": lambda: E.encode(E.FixedBitWidth(bit_width=13), rng.integers(0, 1 << 13, 100_000).astype(np.uint32), W.INT32),
+    "small/fbw/i32/w13/10K": lambda: E.encode(E.FixedBitWidth(bit_width=13), rng.integers(0, 1 << 13, 10_000).astype(np.uint32), W.INT32),
     "mainly/i64/95%/sparse": lambda: mainly(W.INT64, np.uint64, 0.95, E.SparseBool()),
     "mainly/f32/70%/bitmap": lambda: mainly(W.FLOAT, np.uint32, 0.7, E.Trivial()),
     "dict/i64/A64": lambda: dict_num(W.INT64, np.uint64, 64),
@@ -85,10 +90,10 @@ def main():
         enc = make()
         n = int(np.frombuffer(enc[2:6], dtype=np.uint32)[0])
         k = max(1, target // n)
-        pad = (-len(enc)) % 16 + 3  # deliberately misaligned chunk starts
-        blob = enc + bytes(pad)
-        buf = np.frombuffer(blob * k, dtype=np.uint8)
-        plan = Plan(buf, [(i * len(blob), len(enc)) for i in range(k)], per_kernel=PER_KERNEL)
+        shift = int(os.environ.get("NBL_SHIFT", "3"))  # chunk starts at 16*n + shift: misaligned on purpose
+        blob = enc + bytes((-len(enc)) % 16)
+        buf = np.frombuffer(bytes(shift) + blob * k, dtype=np.uint8)
+        plan = Plan(buf, [(shift + i * len(blob), len(enc)) for i in range(k)], per_kernel=PER_KERNEL)
         dec = BatchDecoder(plan)
         dec.stage()
         for _ in range(3):
