@@ -1141,11 +1141,10 @@ __device__ __forceinline__ void body_select_bits(const KArgs& a, const NodeDesc&
 // in the arena, or materialised into work), so the gather is one load per row;
 // all index loads of a batch are issued first, then all gathers, then the stores.
 template <int ES>
-__device__ __forceinline__ void body_dict_gather(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t*) {
+__device__ __forceinline__ void body_dict_gather(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
   using T = typename ElemT<ES>::type;
   constexpr uint32_t V = 16 / ES;
   constexpr uint32_t TE = kTileBytes / ES;
-  constexpr uint32_t B = kBatch<ES>;
   const uint64_t rows = nd.rows;
   const uint64_t start = (uint64_t)tile * TE;
   const uint32_t tile_rows = rows - start < TE ? (uint32_t)(rows - start) : TE;
@@ -1162,35 +1161,111 @@ __device__ __forceinline__ void body_dict_gather(const KArgs& a, const NodeDesc&
     return;
   }
   const Reader<RK_PTR, ES> alpha(nd.c1, a);
+  // A small alphabet (<= 16 KiB) is copied to LDS once per tile with coalesced
+  // loads; the per-row gathers then stay on chip.  Larger ones are gathered from
+  // global memory (L2 resident up to a few MiB).
+  const bool staged = (uint64_t)A * ES <= kTileBytes;
+  T* s_alpha = reinterpret_cast<T*>(smem);
+  if (staged) {
+    constexpr uint32_t SB = ES >= 4 ? 8 : 2;  // loads in flight per thread (register budget of the narrow types)
+    for (uint32_t j0 = threadIdx.x; j0 < A; j0 += SB * kBlock) {
+      T t[SB];
+#pragma unroll
+      for (uint32_t u = 0; u < SB; ++u) {
+        const uint32_t j = j0 + u * kBlock;
+        t[u] = alpha.get(j < A ? j : A - 1);
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < SB; ++u) {
+        const uint32_t j = j0 + u * kBlock;
+        if (j < A) s_alpha[j] = t[u];
+      }
+    }
+  }
   bool bad = false;
   with_reader<4>(nd.c0, a, [&](auto rd) {
     const auto idx = rd.view(start);
+    if constexpr (ES == 8) {
+      // every index of the tile (8 per thread) is requested before the alphabet copy is waited for
+      uint32_t ix[4][V];
 #pragma unroll
-    for (uint32_t ib = 0; ib < 4; ib += B) {
-      uint32_t ix[B][V];
-#pragma unroll
-      for (uint32_t u = 0; u < B; ++u) {
-        const uint32_t q0 = ((ib + u) * kBlock + threadIdx.x) * V;
+      for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t q0 = (u * kBlock + threadIdx.x) * V;
 #pragma unroll
         for (uint32_t j = 0; j < V; ++j) ix[u][j] = idx.at(q0 + j < tile_rows ? q0 + j : tile_rows - 1);
       }
-      T x[B][V];
+      if (staged) __syncthreads();
+      T x[4][V];
 #pragma unroll
-      for (uint32_t u = 0; u < B; ++u)
+      for (uint32_t u = 0; u < 4; ++u)
 #pragma unroll
-        for (uint32_t j = 0; j < V; ++j) {
-          uint32_t i = ix[u][j];
-          if (i >= A) { bad = true; i = A - 1; }
-          x[u][j] = alpha.get(i);
-        }
+        for (uint32_t j = 0; j < V; ++j)
+          if (ix[u][j] >= A) { bad = true; ix[u][j] = A - 1; }
+      if (staged) {  // one uniform branch around straight-line gathers
 #pragma unroll
-      for (uint32_t u = 0; u < B; ++u) {
-        const uint32_t q0 = ((ib + u) * kBlock + threadIdx.x) * V;
+        for (uint32_t u = 0; u < 4; ++u)
+#pragma unroll
+          for (uint32_t j = 0; j < V; ++j) x[u][j] = s_alpha[ix[u][j]];
+      } else {
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u)
+#pragma unroll
+          for (uint32_t j = 0; j < V; ++j) x[u][j] = alpha.get(ix[u][j]);
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 4; ++u) {
+        const uint32_t q0 = (u * kBlock + threadIdx.x) * V;
         if (q0 < tile_rows) {
           Vec16<ES> o;
-#pragma unroll
-          for (uint32_t j = 0; j < V; ++j) o.v[j] = x[u][j];
+          o.v[0] = x[u][0]; o.v[1] = x[u][1];
           store_vec<ES>(dst, q0, tile_rows, o);
+        }
+      }
+    } else {
+      // narrower rows: groups of at most eight rows -- eight index loads, then eight gathers, in flight
+      constexpr uint32_t G = V < 8 ? V : 8;     // rows per group
+      constexpr uint32_t GU = 8 / G;            // rounds per group (2 for 4-byte rows, else 1)
+      if (staged) __syncthreads();
+#pragma unroll
+      for (uint32_t ib = 0; ib < 4; ib += GU) {
+        Vec16<ES> o[GU];
+#pragma unroll
+        for (uint32_t u = 0; u < GU; ++u) o[u].q = make_u32x4(0, 0, 0, 0);
+#pragma unroll
+        for (uint32_t g = 0; g < V; g += G) {
+          uint32_t ix[GU][G];
+#pragma unroll
+          for (uint32_t u = 0; u < GU; ++u) {
+            const uint32_t q0 = ((ib + u) * kBlock + threadIdx.x) * V + g;
+#pragma unroll
+            for (uint32_t j = 0; j < G; ++j) ix[u][j] = idx.at(q0 + j < tile_rows ? q0 + j : tile_rows - 1);
+          }
+#pragma unroll
+          for (uint32_t u = 0; u < GU; ++u)
+#pragma unroll
+            for (uint32_t j = 0; j < G; ++j)
+              if (ix[u][j] >= A) { bad = true; ix[u][j] = A - 1; }
+          T x[GU][G];
+          if (staged) {  // one uniform branch around straight-line gathers
+#pragma unroll
+            for (uint32_t u = 0; u < GU; ++u)
+#pragma unroll
+              for (uint32_t j = 0; j < G; ++j) x[u][j] = s_alpha[ix[u][j]];
+          } else {
+#pragma unroll
+            for (uint32_t u = 0; u < GU; ++u)
+#pragma unroll
+              for (uint32_t j = 0; j < G; ++j) x[u][j] = alpha.get(ix[u][j]);
+          }
+#pragma unroll
+          for (uint32_t u = 0; u < GU; ++u)
+#pragma unroll
+            for (uint32_t j = 0; j < G; ++j) vec_set<ES>(o[u], g + j, x[u][j]);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < GU; ++u) {
+          const uint32_t q0 = ((ib + u) * kBlock + threadIdx.x) * V;
+          if (q0 < tile_rows) store_vec<ES>(dst, q0, tile_rows, o[u]);
         }
       }
     }
