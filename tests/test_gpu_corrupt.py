@@ -1,0 +1,137 @@
+"""GPU: payloads whose headers are well formed but whose DATA is inconsistent
+(run lengths that do not add up, dictionary indices past the alphabet, ...).
+The reference meets these inside its decode loops (NIMBLE_CHECK in
+RLEEncoding.h:289-301, DictionaryEncoding.h:227-236, ...); here every kernel
+clamps the data-dependent index, finishes, and raises a status bit that
+nbl_decode_status reports as NBL_ERR_DEVICE_DATA.  Also: empty chunks."""
+import struct
+
+import numpy as np
+import pytest
+
+from nimble_amd import capi
+from nimble_amd import encoder as E
+from nimble_amd import wire as W
+from nimble_amd.decoder import BatchDecoder, Plan
+
+from util import check_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _decode_expect_device_data(encodings, match):
+    for per_kernel in (False, True):
+        plan = Plan.from_encodings(encodings, per_kernel=per_kernel)
+        dec = BatchDecoder(plan)
+        dec.stage()
+        dec.decode()
+        with pytest.raises(capi.NimbleError, match=match) as ei:
+            dec.status()
+        assert ei.value.status == capi.NBL_ERR_DEVICE_DATA
+        dec.fetch()  # outputs are defined memory, whatever they hold
+        plan.close()
+
+
+def _rle(dtype, rows, lengths, values, lengths_spec=None):
+    lens = E.encode(lengths_spec or E.FixedBitWidth(), np.asarray(lengths, dtype=np.uint32), W.UINT32)
+    vals = E.encode(E.Trivial(), np.asarray(values).astype(W.physical_dtype(dtype)), dtype)
+    return E.prefix(W.RLE, dtype, rows) + struct.pack("<I", len(lens)) + lens + vals
+
+
+def test_rle_lengths_do_not_add_up(gpu):
+    rng = np.random.default_rng(1)
+    for rows, lengths in ((5000, [1000, 1000, 1000]),            # too short
+                          (5000, [4000, 4000, 4000]),            # too long
+                          (70_000, rng.integers(1, 9, 3000)),    # many runs, short
+                          (100, [2**31, 2**31, 2**31, 7])):      # 32-bit wrap of the run ends
+        values = np.arange(len(lengths)) + 5
+        good_sum = int(np.sum(np.asarray(lengths, dtype=np.uint64)) & 0xFFFFFFFF) == rows
+        assert not good_sum
+        _decode_expect_device_data([_rle(W.INT64, rows, lengths, values), _rle(W.INT16, rows, lengths, values)], "run lengths")
+
+
+def test_rle_zero_length_runs_decode_like_the_oracle(gpu, oracle):
+    # zero-length runs are tolerated (they contribute no rows): the slow path resolves them
+    lengths = [3, 0, 0, 4, 0, 5, 0]
+    values = [10, 11, 12, 13, 14, 15, 16]
+    check_parity(oracle, [_rle(W.INT32, 12, lengths, values), _rle(W.INT64, 12, lengths, values)])
+
+
+def test_dictionary_index_out_of_range(gpu):
+    for dtype, npt in ((W.INT64, np.uint64), (W.INT32, np.uint32), (W.INT8, np.uint8)):
+        alpha = E.encode(E.Trivial(), np.arange(10, dtype=npt), dtype)
+        idx = np.arange(3000, dtype=np.uint32) % 10
+        idx[[5, 1700, 2999]] = (10, 4_000_000_000, 77)
+        ind = E.encode(E.Trivial(), idx, W.UINT32)
+        enc = E.prefix(W.DICTIONARY, dtype, idx.size) + struct.pack("<I", len(alpha)) + alpha + ind
+        _decode_expect_device_data([enc], "dictionary index")
+
+
+def test_nullable_count_mismatch(gpu):
+    rows = 9000
+    mask = np.random.default_rng(2).random(rows) < 0.5
+    nulls = E.encode(E.Trivial(), mask, W.BOOL)
+    for delta in (-7, +7, -int(mask.sum())):
+        nn = int(mask.sum()) + delta
+        if nn <= 0:
+            nn = 1
+        data = E.encode(E.Trivial(), np.arange(nn, dtype=np.uint32), W.INT32)
+        enc = E.prefix(W.NULLABLE, W.INT32, rows) + struct.pack("<I", len(data)) + data + nulls
+        _decode_expect_device_data([enc], "selected-row count")
+
+
+def test_varint_truncated(gpu):
+    v = np.random.default_rng(3).integers(0, 1 << 40, 5000).astype(np.uint64)
+    enc = E.encode(E.Varint(), v, W.INT64)
+    _decode_expect_device_data([enc[: len(enc) - 300]], "fewer varints")
+
+
+def test_string_lengths_exceed_blob(gpu):
+    lengths = np.full(100, 10, dtype=np.uint32)
+    lens = E.encode(E.FixedBitWidth(), lengths, W.UINT32)
+    enc = (E.prefix(W.TRIVIAL, W.STRING, 100) + bytes([W.UNCOMPRESSED]) + struct.pack("<I", len(lens)) + lens + bytes(500))
+    plan = Plan.from_encodings([enc])
+    dec = BatchDecoder(plan)
+    dec.stage()
+    dec.decode()
+    with pytest.raises(capi.NimbleError, match="string lengths") as ei:
+        dec.status()
+    assert ei.value.status == capi.NBL_ERR_DEVICE_DATA
+    plan.close()
+
+
+def test_sparse_bool_positions_out_of_range_or_unsorted(gpu):
+    # positions past the row count / out of order never address outside the bitmap
+    rows = 40_000
+    for idx in ([5, 9, 50_000, 60_000, rows], [30_000, 10, 20_000, 5, rows], [2**32 - 1] * 50 + [rows]):
+        ind = E.encode(E.Trivial(), np.asarray(idx, dtype=np.uint32), W.UINT32)
+        enc = E.prefix(W.SPARSE_BOOL, W.BOOL, rows) + bytes([1]) + ind
+        plan = Plan.from_encodings([enc])
+        dec = BatchDecoder(plan)
+        dec.stage()
+        dec.decode()
+        dec.status()  # no status bit: the reference does not validate these either
+        out = dec.fetch()[0].values
+        assert out.size == rows and set(np.unique(out)) <= {0, 1}
+        plan.close()
+
+
+def test_empty_chunks(gpu, oracle):
+    """rowCount == 0 for every encoding that can be empty (EncodingTest.cpp covers
+    empty inputs for all but Constant / MainlyConstant, which cannot be)."""
+    empty32 = np.zeros(0, dtype=np.uint32)
+    encs = [
+        E.encode(E.Trivial(), empty32, W.INT32),
+        E.encode(E.FixedBitWidth(), np.zeros(0, dtype=np.uint64), W.INT64),
+        E.encode(E.Varint(), empty32, W.UINT32),
+        E.encode(E.RLE(), empty32, W.INT32),
+        E.encode(E.Dictionary(), np.zeros(0, dtype=np.uint16), W.INT16),
+        E.encode(E.Trivial(), np.zeros(0, dtype=bool), W.BOOL),
+        E.encode(E.SparseBool(), np.zeros(0, dtype=bool), W.BOOL),
+        E.encode(E.RLE(), np.zeros(0, dtype=bool), W.BOOL),
+        E.encode(E.Trivial(), E.StringColumn.from_list([]), W.STRING),
+        E.encode_nullable(E.Nullable(), empty32, np.zeros(0, dtype=bool), W.INT32),
+        E.encode(E.FixedBitWidth(), np.arange(7, dtype=np.uint32), W.INT32),  # a non-empty neighbour in the same batch
+    ]
+    res = check_parity(oracle, encs)
+    assert [r.rows for r in res] == [0] * 10 + [7]
