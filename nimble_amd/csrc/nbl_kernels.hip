@@ -656,29 +656,31 @@ __device__ __forceinline__ void body_reduce_popc(const KArgs& a, const NodeDesc&
 
 // A varint starts at payload byte b when b == 0 or byte b-1 has its high bit
 // clear (common/Varint.h:78-81).  Tile = kVarintTile payload bytes.
-__device__ __forceinline__ uint32_t varint_start_mask16(const uint8_t* payload, uint64_t len, uint64_t b0) {
-  // bit j set <=> byte b0+j starts a varint; b0 is a multiple of 16, b0 < len
-  uint8_t prev[17];
-  if (b0 == 0) {
-    prev[0] = 0;
-    __builtin_memcpy(prev + 1, payload, 16);
-  } else {
-    __builtin_memcpy(prev, payload + b0 - 1, 17);  // arena slop keeps this readable
-  }
-  uint32_t m = 0;
-#pragma unroll
-  for (uint32_t j = 0; j < 16; ++j)
-    if (b0 + j < len && !(prev[j] & 0x80)) m |= 1u << j;
-  return m;
-}
+// Number of varints that start in the tile = number of bytes in
+// [t0 - 1, t0 + tile_len - 1) whose high bit is clear (the byte before the
+// payload counts as clear).  That range is read with aligned 16-byte loads.
 __device__ __forceinline__ void body_reduce_varint(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
   uint32_t* tmp = reinterpret_cast<uint32_t*>(smem);
   const uint8_t* payload = a.arena + nd.c0.off;
   const uint64_t len = nd.aux2;
-  const uint64_t b0 = (uint64_t)tile * kVarintTile + (uint64_t)threadIdx.x * 16;
-  uint32_t s = 0;
-  if (b0 < len) s = (uint32_t)__popc(varint_start_mask16(payload, len, b0));
-  const uint32_t tot = block_sum(s, tmp);
+  const uint64_t t0 = (uint64_t)tile * kVarintTile;
+  const uint32_t tile_len = len - t0 < kVarintTile ? (uint32_t)(len - t0) : kVarintTile;
+  const uint8_t* first = payload + t0 - 1;                       // inside the arena: an encoding prefix precedes every payload
+  const uint32_t s0 = (uint32_t)(reinterpret_cast<uintptr_t>(first) & 15u);
+  const u32x4* base = reinterpret_cast<const u32x4*>(first - s0);
+  const uint32_t lo = s0 + (tile == 0 ? 1u : 0u), hi = s0 + tile_len;  // counted bytes: [lo, hi) relative to base
+  uint32_t cnt = 0;
+  for (uint32_t i = threadIdx.x; i * 16 < hi; i += kBlock) {
+    const u32x4 v = base[i];
+    auto clear_bits = [](uint32_t d) { const uint32_t t = ~d & 0x80808080u; return ((t >> 7) | (t >> 14) | (t >> 21) | (t >> 28)) & 0xFu; };
+    uint32_t c = clear_bits(v.x) | (clear_bits(v.y) << 4) | (clear_bits(v.z) << 8) | (clear_bits(v.w) << 12);
+    const uint32_t b0 = i * 16;
+    if (b0 < lo) c &= ~((1u << (lo - b0 > 16 ? 16 : lo - b0)) - 1u);
+    if (b0 + 16 > hi) c &= (1u << (hi - b0)) - 1u;
+    cnt += (uint32_t)__popc(c);
+  }
+  if (tile == 0 && threadIdx.x == 0 && tile_len) cnt += 1;      // the first byte of the payload always starts a value
+  const uint32_t tot = block_sum(cnt, tmp);
   if (threadIdx.x == 0) a.parts[nd.part_base + tile] = tot;
 }
 
@@ -1276,38 +1278,79 @@ __device__ __forceinline__ void body_dict_gather(const KArgs& a, const NodeDesc&
 // ----------------------------------------------------------- K_VARINT_DECODE
 // VarintEncoding::materialize (encodings/VarintEncoding.h:119-140): LEB128,
 // low 7 bits first, + baseline (common/Varint.h:83-143 for the byte limits).
+// The tile's payload bytes (4 KiB + 9 bytes of look-ahead) are staged in LDS.
+// Pass 1: every thread finds the varint starts among its 16 bytes and appends
+// their offsets to a list in LDS at their rank.  Pass 2: lane i decodes varint
+// i of the tile from LDS, so the work is balanced whatever the lengths are and
+// the stores of a wave are consecutive.
 template <int ES>
 __device__ __forceinline__ void body_varint_decode(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
   using T = typename ElemT<ES>::type;
-  constexpr uint32_t MAXB = ES == 4 ? 5 : 10;
-  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem);
+  u32x4* stage = reinterpret_cast<u32x4*>(smem);                        // <= 16 + 4096 + 10 + 15 + 4 bytes
+  uint16_t* s_start = reinterpret_cast<uint16_t*>(smem + 8192);          // <= 4096 offsets
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + kTileBytes + 3072);
   const uint8_t* payload = a.arena + nd.c0.off;
   const uint64_t len = nd.aux2;
   const uint64_t rows = nd.rows;
   const T base = (T)nd.c0.base;
   T* dst = reinterpret_cast<T*>(self_ptr(nd, a));
-  const uint64_t b0 = (uint64_t)tile * kVarintTile + (uint64_t)threadIdx.x * 16;
+  const uint64_t t0 = (uint64_t)tile * kVarintTile;                      // < len: the tile exists
+  const uint32_t tile_len = len - t0 < kVarintTile ? (uint32_t)(len - t0) : kVarintTile;
+  const uint32_t lead = tile ? 16u : 0u;                                 // bytes staged ahead of the tile: the previous byte decides whether byte 0 starts a value
+  const uint32_t mis = stage_tile<2>(payload + t0 - lead, lead + tile_len + 10u, stage);
+  __syncthreads();
+  const uint8_t* s8 = reinterpret_cast<const uint8_t*>(stage);
+  const uint32_t* s32 = reinterpret_cast<const uint32_t*>(stage);
+  const uint32_t org = mis + lead;                                       // LDS byte of the tile's first payload byte
+  // pass 1: start mask of this thread's 16 bytes
+  const uint32_t o0 = threadIdx.x * 16;
   uint32_t m = 0;
-  if (b0 < len) m = varint_start_mask16(payload, len, b0);
-  uint32_t total;
-  uint64_t rank = (uint64_t)a.parts[nd.part_base + tile] + block_excl_scan((uint32_t)__popc(m), tmp, total);
-  if (tile == 0 && threadIdx.x == 0 && a.totals[nd.total_idx] < nd.rows) atomicOr(a.status, ST_VARINT_COUNT);
+  if (o0 < tile_len) {
+    uint32_t n0, n1, n2, n3;
+    lds_window(s32, (org + o0) * 8u, n0, n1, n2, n3);
+    auto high_bits = [](uint32_t d) { const uint32_t t = d & 0x80808080u; return ((t >> 7) | (t >> 14) | (t >> 21) | (t >> 28)) & 0xFu; };
+    const uint32_t hb = high_bits(n0) | (high_bits(n1) << 4) | (high_bits(n2) << 8) | (high_bits(n3) << 12);
+    const uint32_t prev = (tile | threadIdx.x) ? (uint32_t)(s8[org + o0 - 1] >> 7) : 0u;  // the very first byte always starts a value
+    const uint32_t valid = tile_len - o0 >= 16 ? 0xFFFFu : ((1u << (tile_len - o0)) - 1u);
+    m = ~((hb << 1) | prev) & valid;
+  }
+  uint32_t count;
+  uint32_t k = block_excl_scan((uint32_t)__popc(m), tmp, count);
   while (m) {
     const uint32_t j = (uint32_t)__ffs((int)m) - 1u;
     m &= m - 1;
-    if (rank < rows) {
-      const uint8_t* p = payload + b0 + j;
-      uint64_t v = 0;
-#pragma unroll
-      for (uint32_t k = 0; k < MAXB; ++k) {
-        // bytes past the payload end (truncated input) read the arena slop / next bytes: never out of the arena
-        const uint8_t byte = (b0 + j + k < len) ? p[k] : 0;
-        v |= (uint64_t)(byte & 0x7F) << (7 * k);
-        if (!(byte & 0x80)) break;
-      }
-      dst[rank] = (T)((T)v + base);
+    s_start[k++] = (uint16_t)(o0 + j);
+  }
+  __syncthreads();
+  if (tile == 0 && threadIdx.x == 0 && a.totals[nd.total_idx] < nd.rows) atomicOr(a.status, ST_VARINT_COUNT);
+  // pass 2
+  const uint64_t rank0 = a.parts[nd.part_base + tile];
+  for (uint32_t i = threadIdx.x; i < count; i += kBlock) {
+    if (rank0 + i >= rows) break;
+    const uint32_t off = s_start[i];
+    const uint64_t avail = len - (t0 + off);                             // payload bytes from this start on (>= 1)
+    const uint32_t L = org + off;
+    const uint32_t d0 = L >> 2, S = (L & 3u) * 8u;
+    const uint32_t w0 = s32[d0], w1 = s32[d0 + 1], w2 = s32[d0 + 2], w3 = s32[d0 + 3];
+    uint64_t lo = (uint64_t)__builtin_amdgcn_alignbit(w1, w0, S) | ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, S) << 32);  // bytes 0..7
+    uint32_t hi = __builtin_amdgcn_alignbit(w3, w2, S);                                                                          // bytes 8..11
+    if (avail < 8) lo &= (1ull << (8 * (uint32_t)avail)) - 1ull;         // a truncated payload reads as zero bytes
+    if (avail < 10) hi &= avail <= 8 ? 0u : 0xFFu;
+    // the value ends at the first byte whose high bit is clear
+    const uint64_t stop = ~lo & 0x8080808080808080ull;
+    uint64_t x = lo & 0x7F7F7F7F7F7F7F7Full;                             // 8 groups of 7 bits ...
+    x = ((x & 0x7F007F007F007F00ull) >> 1) | (x & 0x007F007F007F007Full);
+    x = ((x & 0x3FFF00003FFF0000ull) >> 2) | (x & 0x00003FFF00003FFFull);
+    x = ((x & 0x0FFFFFFF00000000ull) >> 4) | (x & 0x000000000FFFFFFFull);  // ... packed into 56 bits
+    uint64_t v;
+    if (stop) {
+      const uint32_t nbytes = ((uint32_t)__ffsll((unsigned long long)stop) >> 3);  // 1..8
+      v = nbytes == 8 ? x : (x & ((1ull << (7 * nbytes)) - 1ull));
+    } else {
+      v = x | ((uint64_t)(hi & 0x7Fu) << 56);
+      if (hi & 0x80u) v |= (uint64_t)((hi >> 8) & 0x7Fu) << 63;
     }
-    ++rank;
+    dst[rank0 + i] = (T)((T)v + base);
   }
 }
 
