@@ -703,6 +703,11 @@ __device__ __forceinline__ void body_scan_tiles(const KArgs& a, const NodeDesc& 
   if (threadIdx.x == 0) a.totals[nd.total_idx] = carry;
 }
 
+// first_run[] of an RLE node sits behind its run-end array (R entries, 16-byte rounded)
+__device__ __forceinline__ uint32_t* rle_first_run(const KArgs& a, const NodeDesc& nd) {
+  return reinterpret_cast<uint32_t*>(a.work + nd.aux_off) + (((uint64_t)nd.c0.rows + 3) & ~3ull);
+}
+
 // ---------------------------------------------------------------- K_RLE_ENDS
 // ends[k] = len[0] + ... + len[k]; flags zero-length runs in totals[total_idx+1].
 __device__ __forceinline__ void body_rle_ends(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
@@ -741,6 +746,24 @@ __device__ __forceinline__ void body_rle_ends(const KArgs& a, const NodeDesc& nd
       if (e0 + j < n) ends[e0 + j] = v[j] + ex;
   }
   if (__ballot(zero) != 0 && lane_id() == 0) atomicOr(&a.totals[nd.total_idx + 1], 1u);
+  // first_run[t] = the run that holds row t * tile_rows, for every output tile t:
+  // run i covers rows [start, end), so it is the first run of every tile whose
+  // first row falls inside it.  Spares the expand step a search per tile.
+  uint32_t* first_run = rle_first_run(a, nd);
+  const uint32_t tile_rows = (uint32_t)nd.aux2;
+  const uint64_t rows = nd.rows;
+  uint32_t start = ex;
+#pragma unroll
+  for (uint32_t j = 0; j < 8; ++j) {
+    const uint32_t end = v[j] + ex;
+    if (e0 + j < n && end > start) {  // wrapped sums (corrupt lengths) have end <= start and write nothing
+      const uint64_t last_row = (uint64_t)end - 1 < rows ? (uint64_t)end - 1 : rows - 1;
+      const uint32_t t_hi = (uint32_t)(last_row / tile_rows);
+#pragma unroll 1
+      for (uint32_t t = (uint32_t)(((uint64_t)start + tile_rows - 1) / tile_rows); t <= t_hi; ++t) first_run[t] = (uint32_t)(e0 + j);
+    }
+    start = end;
+  }
 }
 
 // -------------------------------------------------------------- K_RLE_EXPAND
@@ -795,12 +818,26 @@ __device__ __forceinline__ void body_rle_expand(const KArgs& a, const NodeDesc& 
     }
     return;
   }
-  find_run_range(ends, R, p0, p1, s_k);
+  const bool zero_runs = a.totals[nd.total_idx + 1] != 0;
+  if (zero_runs) {
+    find_run_range(ends, R, p0, p1, s_k);
+  } else if (threadIdx.x == 0) {
+    // runs of the tile: from the run holding its first row to the run holding the
+    // next tile's first row (clamped: these come from payload data)
+    const uint32_t* first_run = rle_first_run(a, nd);
+    const uint32_t f0 = first_run[tile];
+    const uint32_t f1 = p0 + TE < rows ? first_run[tile + 1] : R - 1;
+    const uint32_t c0 = f0 < R ? f0 : R - 1;
+    uint32_t c1 = f1 < R ? f1 : R - 1;
+    if (c1 < c0) c1 = c0;
+    if (c1 - c0 >= TE) c1 = c0 + TE - 1;  // a tile of TE rows meets at most TE non-empty runs
+    s_k[0] = c0; s_k[1] = c1;
+  }
   if (threadIdx.x < W) s_bits[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t k0 = s_k[0], k1 = s_k[1] < s_k[0] ? s_k[0] : s_k[1];
   const uint32_t nruns = k1 - k0 + 1;
-  const bool slow = a.totals[nd.total_idx + 1] != 0 || nruns > TE;
+  const bool slow = zero_runs || nruns > TE;
   if (!slow) {
     uint32_t* bits32 = reinterpret_cast<uint32_t*>(s_bits);
     for (uint32_t j = k0 + threadIdx.x; j < k1; j += kBlock) {
@@ -869,11 +906,20 @@ __device__ __forceinline__ void body_rle_expand_bool(const KArgs& a, const NodeD
     if (w * 64 < rows) dst[w] = 0;
     return;
   }
-  find_run_range(ends, R, p0, p1, s_k);
+  const bool slow = a.totals[nd.total_idx + 1] != 0;
+  if (slow) {
+    find_run_range(ends, R, p0, p1, s_k);
+  } else if (threadIdx.x == 0) {
+    const uint32_t* first_run = rle_first_run(a, nd);
+    const uint32_t f0 = first_run[tile];
+    const uint32_t f1 = p0 + kBitTileRows < rows ? first_run[tile + 1] : R - 1;
+    const uint32_t c0 = f0 < R ? f0 : R - 1;
+    const uint32_t c1 = f1 < R ? f1 : R - 1;
+    s_k[0] = c0; s_k[1] = c1 < c0 ? c0 : c1;
+  }
   s_bits[threadIdx.x] = 0;
   __syncthreads();
   const uint32_t k0 = s_k[0], k1 = s_k[1] < s_k[0] ? s_k[0] : s_k[1];
-  const bool slow = a.totals[nd.total_idx + 1] != 0;
   if (!slow) {
     uint32_t* bits32 = reinterpret_cast<uint32_t*>(s_bits);
     for (uint32_t j = k0 + threadIdx.x; j < k1; j += kBlock) {

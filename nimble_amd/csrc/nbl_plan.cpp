@@ -515,7 +515,10 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       d.c0.rows = R;
       const uint32_t nt = div_up32(R, kScanTile);
       alloc_scan(d, nt);
-      d.aux_off = alloc_work((uint64_t)R * 4);
+      // run ends (R entries, 16-byte rounded) followed by first_run[] (one entry per output tile)
+      const uint32_t out_tile_rows = nn.is_bool ? kBitTileRows : tile_rows;
+      d.aux2 = out_tile_rows;
+      d.aux_off = alloc_work((((uint64_t)R + 3) & ~3ull) * 4 + (uint64_t)div_up32(rows, out_tile_rows) * 4);
       if (nn.is_bool) {
         d.self = bits_ref();
         if (nn.flag) d.flags |= NF_FIRST_TRUE;
