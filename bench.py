@@ -39,6 +39,8 @@ def parse_args():
     ap.add_argument("--no-breakdown", action="store_true", help="skip the per-operation profile of the unfused plan")
     ap.add_argument("--cpu-sample-chunks", type=int, default=0, help="0 = first chunk of every column")
     ap.add_argument("--check", action="store_true", help="verify a sample of the output against the oracle")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for N>1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)")
     return ap.parse_args()
 
 
@@ -111,7 +113,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        else:
+            dist.init_process_group(backend="gloo")
+            local_rank %= torch.cuda.device_count()  # rehearsal: ranks share the visible GPUs
     n_gpus = max(world, 1)
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
@@ -122,9 +128,9 @@ def main():
     t_gen = time.perf_counter()
     # one stripe of identical shape per GPU (weak scaling); ownership by the same
     # assignment a file reader uses, computed on every rank without communication
-    stripe = shard.assign_stripes([args.rows] * n_gpus, n_gpus)[rank][0]
     default_rows = {"fbw_rle": 10_000_000, "dict_string": 10_000_000, "mixed": 1_250_000, "wide": 100_000}
     args.rows = args.rows or default_rows[args.workload]
+    stripe = shard.assign_stripes([args.rows] * n_gpus, n_gpus)[rank][0]
     chunks = workloads.WORKLOADS[args.workload](args.rows, 42 + stripe)
     buf, offs = workloads.pack_chunks(chunks)
     t_gen = time.perf_counter() - t_gen

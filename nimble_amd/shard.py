@@ -17,7 +17,7 @@ from typing import Callable, Dict, List, Sequence
 
 def assign_stripes(stripe_sizes: Sequence[int], world: int) -> List[List[int]]:
     """Longest-processing-time greedy: stripes in decreasing size, each to the
-    rank with the least bytes so far (ties: lowest rank).  Deterministic, so
+    rank with the least bytes so far (ties: fewest stripes, then lowest rank).  Deterministic, so
     every rank computes the same assignment from the footer's stripe sizes
     without communicating.  Returns, per rank, its stripe indices ascending."""
     if world < 1:
@@ -25,7 +25,7 @@ def assign_stripes(stripe_sizes: Sequence[int], world: int) -> List[List[int]]:
     load = [0] * world
     owned: List[List[int]] = [[] for _ in range(world)]
     for s in sorted(range(len(stripe_sizes)), key=lambda i: (-int(stripe_sizes[i]), i)):
-        r = min(range(world), key=lambda k: (load[k], k))
+        r = min(range(world), key=lambda k: (load[k], len(owned[k]), k))
         owned[r].append(s)
         load[r] += int(stripe_sizes[s])
     return [sorted(o) for o in owned]

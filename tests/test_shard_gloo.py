@@ -35,6 +35,8 @@ def test_lpt_assignment_properties():
     # equal stripes: rank r gets stripes r, r+world, ...
     assert shard.assign_stripes([7] * 8, 4) == [[0, 4], [1, 5], [2, 6], [3, 7]]
     assert shard.imbalance([7] * 8, shard.assign_stripes([7] * 8, 4)) == 1.0
+    # empty stripes still spread over the ranks (one each), they do not pile up on rank 0
+    assert shard.assign_stripes([0, 0, 0], 3) == [[0], [1], [2]]
 
 
 def test_units_fall_back_to_streams_when_few_stripes():
