@@ -103,6 +103,45 @@ def pcie_inclusive(dec, plan, torch, device, steps=5):
             "link_gbs": round((enc + int(plan.info.out_bytes)) / dt / 1e9, 2)}
 
 
+def pcie_pipelined(plan, torch, device, n_buffers=2, stripes=8):
+    """Host-to-host rate with stripes in flight on `n_buffers` streams: the H2D of
+    one stripe overlaps the decode and the D2H of the previous one (PCIe is full
+    duplex), which is how a reader would drive the path over many stripes."""
+    from nimble_amd.decoder import BatchDecoder
+
+    enc = int(plan.buffer.size)
+    streams = [torch.cuda.Stream(device=device) for _ in range(n_buffers)]
+    decs, h_in, h_out = [], [], []
+    for s in streams:
+        d = BatchDecoder(plan, str(device), stream=s)
+        with torch.cuda.stream(s):
+            d.stage()
+        decs.append(d)
+        hi = torch.empty(enc, dtype=torch.uint8).pin_memory()
+        hi.numpy()[:] = plan.buffer
+        h_in.append(hi)
+        h_out.append(torch.empty(int(plan.info.out_bytes), dtype=torch.uint8).pin_memory())
+
+    def run(n):
+        for i in range(n):
+            k = i % n_buffers
+            with torch.cuda.stream(streams[k]):
+                decs[k].arena[:enc].copy_(h_in[k], non_blocking=True)
+                decs[k].decode()
+                h_out[k].copy_(decs[k].out, non_blocking=True)
+        torch.cuda.synchronize(device)
+
+    run(n_buffers)
+    t0 = time.perf_counter()
+    run(stripes)
+    dt = (time.perf_counter() - t0) / stripes
+    for d in decs:
+        d.status()
+    decoded = int(plan.info.decoded_bytes)
+    return {"decoded_gbs": round(decoded / dt / 1e9, 2), "ms_per_stripe": round(dt * 1e3, 3), "streams": n_buffers,
+            "stripes": stripes, "h2d_gbs": round(enc / dt / 1e9, 2), "d2h_gbs": round(int(plan.info.out_bytes) / dt / 1e9, 2)}
+
+
 def main():
     args = parse_args()
     import torch
@@ -265,6 +304,7 @@ def main():
 
     if rank == 0 and n_gpus == 1 and not args.no_pcie:
         result["pcie_inclusive"] = pcie_inclusive(dec, plan, torch, device)
+        result["pcie_pipelined"] = pcie_pipelined(plan, torch, device)
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         result["cpu_baseline"] = cpu_baseline(chunks)
     if rank == 0:

@@ -753,9 +753,20 @@ void nbl_plan::finish() {
   for (Step& st : steps)
     if (st.chunk >= 0) st.alg = chunk_alg[(size_t)st.chunk];
   if (fused && last_level > 0) spread_free_steps(last_level);
-  std::stable_sort(steps.begin(), steps.end(), [](const Step& a, const Step& b) {
-    return std::tie(a.level, a.filler, a.kernel, a.es) < std::tie(b.level, b.filler, b.kernel, b.es);
-  });
+  {  // stable counting sort by (level, filler, kernel, element size): wide tables have ~10 steps per column
+    auto key = [](const Step& st) { return (((size_t)st.level * 2 + (st.filler ? 1 : 0)) * K_COUNT + st.kernel) * 4 + es_slot(st.es); };
+    std::vector<uint32_t> first((size_t)(last_level + 1) * 2 * K_COUNT * 4 + 1, 0);
+    for (const Step& st : steps) ++first[key(st) + 1];
+    for (size_t i = 1; i < first.size(); ++i) first[i] += first[i - 1];
+    std::vector<Step> sorted(steps.size());
+    for (const Step& st : steps) sorted[first[key(st)]++] = st;
+    steps.swap(sorted);
+  }
+  {
+    size_t n_tiles_total = 0;
+    for (const Step& st : steps) n_tiles_total += st.n_tiles;
+    tiles.reserve(n_tiles_total);
+  }
   for (size_t i = 0; i < steps.size();) {
     size_t j = i;
     Launch L{steps[i].kernel, steps[i].es, (uint32_t)tiles.size(), 0, steps[i].level, 0, std::string()};
@@ -838,6 +849,13 @@ nbl_status nbl_plan_batch(const uint8_t* base, const uint64_t* offsets, const ui
     p->fused = !(options && options->struct_size >= 12 && (options->flags & NBL_PLAN_PER_KERNEL_LAUNCHES));
     p->layouts.resize(n_chunks);
     for (uint32_t c = 0; c < n_chunks; ++c) p->span = std::max(p->span, offsets[c] + sizes[c]);
+    p->nodes.reserve((size_t)n_chunks * 6);
+    p->dnodes.reserve((size_t)n_chunks * 4);
+    p->aux_in_work.reserve((size_t)n_chunks * 4);
+    p->steps.reserve((size_t)n_chunks * 8);
+    p->roots.reserve(n_chunks);
+    p->chunk_alg.reserve(n_chunks);
+    p->chunk_final_step.reserve(n_chunks);
     for (uint32_t c = 0; c < n_chunks; ++c) p->plan_chunk(c, offsets[c], sizes[c]);
     p->finish();
     p->base = nullptr;  // the host bytes are not needed after planning
