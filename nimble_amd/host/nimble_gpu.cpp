@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <cstring>
 #include <mutex>
+#include <utility>
+#include <vector>
 
 namespace nimble_amd {
 
@@ -26,20 +28,80 @@ void hipCheck(hipError_t e, const char* what) {
 inline bool bitIsSet(const void* bits, uint64_t i) { return (static_cast<const uint8_t*>(bits)[i >> 3] >> (i & 7)) & 1; }
 inline void bitSet(void* bits, uint64_t i) { static_cast<uint8_t*>(bits)[i >> 3] |= uint8_t(1u << (i & 7)); }
 inline void bitClear(void* bits, uint64_t i) { static_cast<uint8_t*>(bits)[i >> 3] &= uint8_t(~(1u << (i & 7))); }
+
+// bits [begin, end) := v; whole bytes with memset
 void fillBits(void* bits, uint64_t begin, uint64_t end, bool v) {
-  for (uint64_t i = begin; i < end; ++i) v ? bitSet(bits, i) : bitClear(bits, i);
+  auto* p = static_cast<uint8_t*>(bits);
+  while (begin < end && (begin & 7)) { v ? bitSet(p, begin) : bitClear(p, begin); ++begin; }
+  const uint64_t whole = (end - begin) >> 3;
+  if (whole) memset(p + (begin >> 3), v ? 0xFF : 0x00, whole);
+  begin += whole << 3;
+  while (begin < end) { v ? bitSet(p, begin) : bitClear(p, begin); ++begin; }
+}
+// f(i) for every set bit i in [begin, end), ascending; never reads a byte outside the range
+template <typename F>
+void forEachSetBit(const void* bits, uint64_t begin, uint64_t end, F&& f) {
+  const auto* p = static_cast<const uint8_t*>(bits);
+  uint64_t i = begin;
+  while (i < end) {
+    if ((i & 7) == 0 && i + 64 <= end) {
+      uint64_t w;
+      memcpy(&w, p + (i >> 3), 8);
+      while (w) { f(i + (uint64_t)__builtin_ctzll(w)); w &= w - 1; }
+      i += 64;
+      continue;
+    }
+    const uint32_t avail = (uint32_t)std::min<uint64_t>(8 - (i & 7), end - i);
+    uint32_t b = (uint32_t)(p[i >> 3] >> (i & 7)) & ((1u << avail) - 1u);
+    while (b) { f(i + (uint64_t)__builtin_ctz(b)); b &= b - 1; }
+    i += avail;
+  }
 }
 uint32_t countBits(const void* bits, uint64_t begin, uint64_t end) {
+  const auto* p = static_cast<const uint8_t*>(bits);
   uint32_t n = 0;
-  for (uint64_t i = begin; i < end; ++i) n += bitIsSet(bits, i);
+  uint64_t i = begin;
+  while (i < end) {
+    if ((i & 7) == 0 && i + 64 <= end) {
+      uint64_t w;
+      memcpy(&w, p + (i >> 3), 8);
+      n += (uint32_t)__builtin_popcountll(w);
+      i += 64;
+      continue;
+    }
+    const uint32_t avail = (uint32_t)std::min<uint64_t>(8 - (i & 7), end - i);
+    n += (uint32_t)__builtin_popcount((uint32_t)(p[i >> 3] >> (i & 7)) & ((1u << avail) - 1u));
+    i += avail;
+  }
   return n;
 }
 // velox::bits::findSetBit: position of the n-th (1-based) set bit in [begin,end), `end` if fewer.
 uint32_t findSetBit(const void* bits, uint32_t begin, uint32_t end, uint32_t n) {
+  if (n == 0) return end;
+  const auto* p = static_cast<const uint8_t*>(bits);
+  uint64_t i = begin;
   uint32_t seen = 0;
-  for (uint32_t i = begin; i < end; ++i)
-    if (bitIsSet(bits, i) && ++seen == n) return i;
+  while (i < end) {
+    const uint32_t avail = (uint32_t)std::min<uint64_t>(8 - (i & 7), end - i);
+    uint32_t b = (uint32_t)(p[i >> 3] >> (i & 7)) & ((1u << avail) - 1u);
+    const uint32_t c = (uint32_t)__builtin_popcount(b);
+    if (seen + c >= n) {
+      for (;; b &= b - 1)
+        if (++seen == n) return (uint32_t)(i + (uint64_t)__builtin_ctz(b));
+    }
+    seen += c;
+    i += avail;
+  }
   return end;
+}
+// dst bits [d, d + n) := src bits [s, s + n)
+void copyBits(void* dst, uint64_t d, const void* src, uint64_t s, uint64_t n) {
+  if (((d | s) & 7) == 0) {
+    memcpy(static_cast<uint8_t*>(dst) + (d >> 3), static_cast<const uint8_t*>(src) + (s >> 3), n >> 3);
+    for (uint64_t i = n & ~7ull; i < n; ++i) bitIsSet(src, s + i) ? bitSet(dst, d + i) : bitClear(dst, d + i);
+    return;
+  }
+  for (uint64_t i = 0; i < n; ++i) bitIsSet(src, s + i) ? bitSet(dst, d + i) : bitClear(dst, d + i);
 }
 
 struct DeviceBuffer {
@@ -50,13 +112,57 @@ struct DeviceBuffer {
     if (ptr) hipCheck(hipFree(ptr), "hipFree");
     ptr = nullptr;
     cap = 0;
-    const size_t want = std::max<size_t>(n, 1 << 20);
+    const size_t want = std::max<size_t>(n + n / 4, 1 << 20);
     hipCheck(hipMalloc(&ptr, want), "hipMalloc");
     cap = want;
   }
   ~DeviceBuffer() {
     if (ptr) (void)hipFree(ptr);
   }
+};
+
+// Pinned host memory, recycled: every batch needs one block for the encoded
+// bytes and one for the decoded output, and the decoded block stays alive as
+// long as any Encoding of the batch does.
+class PinnedPool : public std::enable_shared_from_this<PinnedPool> {
+ public:
+  ~PinnedPool() {
+    for (auto& b : free_) (void)hipHostFree(b.first);
+  }
+  std::shared_ptr<uint8_t> acquire(size_t bytes) {
+    const size_t want = std::max<size_t>(bytes, 4096);
+    void* ptr = nullptr;
+    size_t cap = 0;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      size_t best = free_.size();
+      for (size_t i = 0; i < free_.size(); ++i)
+        if (free_[i].second >= want && (best == free_.size() || free_[i].second < free_[best].second)) best = i;
+      if (best != free_.size() && free_[best].second <= 2 * want + (1 << 20)) {
+        ptr = free_[best].first;
+        cap = free_[best].second;
+        free_.erase(free_.begin() + (long)best);
+      }
+    }
+    if (!ptr) {
+      cap = want + want / 8;
+      hipCheck(hipHostMalloc(&ptr, cap, hipHostMallocDefault), "hipHostMalloc");
+    }
+    auto self = shared_from_this();
+    return std::shared_ptr<uint8_t>(static_cast<uint8_t*>(ptr), [self, cap](uint8_t* p) { self->release(p, cap); });
+  }
+
+ private:
+  void release(void* p, size_t cap) {
+    std::lock_guard<std::mutex> lock(mu_);
+    if (free_.size() >= 8) {  // keep a few blocks, give the rest back
+      (void)hipHostFree(p);
+      return;
+    }
+    free_.emplace_back(p, cap);
+  }
+  std::mutex mu_;
+  std::vector<std::pair<void*, size_t>> free_;
 };
 
 }  // namespace
@@ -71,6 +177,7 @@ class GpuContext {
   int device_;
   hipStream_t stream_ = nullptr;
   DeviceBuffer arena, out, work;
+  std::shared_ptr<PinnedPool> pinned = std::make_shared<PinnedPool>();
   void ensure() {
     hipCheck(hipSetDevice(device_), "hipSetDevice");
     if (!stream_) hipCheck(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
@@ -79,21 +186,23 @@ class GpuContext {
 
 namespace {
 
-// One decoded chunk resident in host memory.
+// One decoded chunk resident in host memory: a window into the batch's pinned
+// output block, which every Encoding of the batch keeps alive (no per-chunk copy).
 class GpuEncoding final : public Encoding {
  public:
-  GpuEncoding(const nbl_chunk_layout& lay, const uint8_t* hostOut, const GpuEncodingFactory::StringBufferFactory& sbf)
-      : lay_(lay) {
+  GpuEncoding(const nbl_chunk_layout& lay, std::shared_ptr<uint8_t> block, const GpuEncodingFactory::StringBufferFactory& sbf)
+      : lay_(lay), block_(std::move(block)) {
     es_ = lay.elem_bytes;
-    values_.assign(hostOut + lay.values_offset, hostOut + lay.values_offset + lay.values_bytes);
-    if (lay.nullable) nulls_.assign(hostOut + lay.nulls_offset, hostOut + lay.nulls_offset + lay.nulls_bytes);
+    const uint8_t* hostOut = block_.get();
+    values_ = hostOut + lay.values_offset;
+    nulls_ = lay.nullable ? hostOut + lay.nulls_offset : nullptr;
     if (lay.data_type == (uint8_t)DataType::String) {
       // string bytes live in memory the caller's factory hands out, as the
       // reference's string encodings do (TrivialEncoding.cpp:129-135)
       char* dst = lay.string_bytes ? static_cast<char*>(sbf(static_cast<uint32_t>(lay.string_bytes))) : nullptr;
       if (lay.string_bytes) memcpy(dst, hostOut + lay.string_offset, lay.string_bytes);
       strings_ = dst;
-      const uint64_t* views = reinterpret_cast<const uint64_t*>(values_.data());
+      const uint64_t* views = reinterpret_cast<const uint64_t*>(values_);
       for (uint32_t i = 0; i < lay.rows; ++i) {
         const uint64_t off = views[i] & 0xFFFFFFFFull, len = views[i] >> 32;
         if (off + len > lay.string_bytes) throw NimbleError(NBL_ERR_DEVICE_DATA, "string view outside the string buffer");
@@ -124,34 +233,38 @@ class GpuEncoding final : public Encoding {
         return n;
       }
       void* nulls = getOutputNulls();
+      copyBits(nulls, offset, scatter->bits, offset, scatterSize);
       uint32_t src = r;
-      for (uint32_t pos = offset; pos < offset + scatterSize; ++pos) {
-        if (scatter->test(pos)) {
-          bitSet(nulls, pos);
-          if (src < r + n) copyRows(src++, 1, buffer, pos);
-        } else {
-          bitClear(nulls, pos);
-        }
-      }
+      const uint32_t stop = r + n;
+      forEachSetBit(scatter->bits, offset, (uint64_t)offset + scatterSize, [&](uint64_t pos) {
+        if (src < stop) copyRows(src++, 1, buffer, (uint32_t)pos);
+      });
       return n;
     }
     // NullableEncoding::materializeNullable, NullableEncoding.h:239-306
-    const uint32_t nonNull = countBits(nulls_.data(), r, (uint64_t)r + n);
+    const uint32_t nonNull = countBits(nulls_, r, (uint64_t)r + n);
     if (nonNull == scatterSize) {  // no nulls in range and no gaps: bitmap untouched
       copyRows(r, n, buffer, offset);
       return nonNull;
     }
     void* nulls = getOutputNulls();
+    if (!scatter) {
+      // row r + i lands in slot offset + i: the null bitmap is a bit copy, values go where the bit is set
+      copyBits(nulls, offset, nulls_, r, n);
+      forEachSetBit(nulls_, r, (uint64_t)r + n, [&](uint64_t row) { copyRows((uint32_t)row, 1, buffer, offset + (uint32_t)(row - r)); });
+      return nonNull;
+    }
     fillBits(nulls, offset, (uint64_t)offset + scatterSize, false);
     uint32_t src = r;
-    for (uint32_t pos = offset; pos < offset + scatterSize && src < r + n; ++pos) {
-      if (scatter && !scatter->test(pos)) continue;
-      if (bitIsSet(nulls_.data(), src)) {
+    const uint32_t stop = r + n;
+    forEachSetBit(scatter->bits, offset, (uint64_t)offset + scatterSize, [&](uint64_t pos) {
+      if (src >= stop) return;
+      if (bitIsSet(nulls_, src)) {
         bitSet(nulls, pos);
-        copyRows(src, 1, buffer, pos);
+        copyRows(src, 1, buffer, (uint32_t)pos);
       }
       ++src;
-    }
+    });
     return nonNull;
   }
 
@@ -172,21 +285,30 @@ class GpuEncoding final : public Encoding {
   void copyRows(uint32_t r, uint32_t n, void* buffer, uint32_t slot) const {
     if (lay_.data_type == (uint8_t)DataType::String) {
       auto* out = static_cast<std::string_view*>(buffer) + slot;
-      const uint64_t* views = reinterpret_cast<const uint64_t*>(values_.data());
+      const uint64_t* views = reinterpret_cast<const uint64_t*>(values_);
       for (uint32_t i = 0; i < n; ++i) {
         const uint64_t v = views[r + i];
         out[i] = std::string_view(strings_ + (v & 0xFFFFFFFFull), static_cast<size_t>(v >> 32));
       }
-    } else {
-      memcpy(static_cast<uint8_t*>(buffer) + (size_t)slot * es_, values_.data() + (size_t)r * es_, (size_t)n * es_);
+      return;
     }
+    if (n == 1) {  // the scatter loops copy row by row: keep that a load and a store
+      switch (es_) {
+        case 8: static_cast<uint64_t*>(buffer)[slot] = reinterpret_cast<const uint64_t*>(values_)[r]; return;
+        case 4: static_cast<uint32_t*>(buffer)[slot] = reinterpret_cast<const uint32_t*>(values_)[r]; return;
+        case 2: static_cast<uint16_t*>(buffer)[slot] = reinterpret_cast<const uint16_t*>(values_)[r]; return;
+        default: static_cast<uint8_t*>(buffer)[slot] = values_[r]; return;
+      }
+    }
+    memcpy(static_cast<uint8_t*>(buffer) + (size_t)slot * es_, values_ + (size_t)r * es_, (size_t)n * es_);
   }
 
   nbl_chunk_layout lay_;
+  std::shared_ptr<uint8_t> block_;
   uint32_t es_ = 0;
   uint32_t row_ = 0;
-  std::vector<uint8_t> values_;
-  std::vector<uint8_t> nulls_;
+  const uint8_t* values_ = nullptr;
+  const uint8_t* nulls_ = nullptr;
   const char* strings_ = nullptr;
 };
 
@@ -200,43 +322,42 @@ std::vector<std::unique_ptr<Encoding>> decodeChunks(GpuContext& ctx, const std::
                                                     const GpuEncodingFactory::StringBufferFactory& sbf, const Options& opts) {
   std::vector<std::unique_ptr<Encoding>> result;
   if (chunks.empty()) return result;
-  // the C ABI wants one base pointer: address chunks relative to the lowest one
-  // when they share a buffer closely, otherwise pack them into a staging buffer
-  std::vector<uint8_t> staging;
+  // the chunks are packed (16-byte aligned starts) into one pinned staging block:
+  // the image the device arena receives
   std::vector<uint64_t> offs(chunks.size()), sizes(chunks.size());
-  uint64_t pos = 0;
+  uint64_t total = 0;
   for (size_t i = 0; i < chunks.size(); ++i) {
-    offs[i] = pos;
+    offs[i] = total;
     sizes[i] = chunks[i].size();
-    pos += (chunks[i].size() + 15) & ~uint64_t(15);
+    total += (chunks[i].size() + 15) & ~uint64_t(15);
   }
-  staging.resize(pos);
-  for (size_t i = 0; i < chunks.size(); ++i) memcpy(staging.data() + offs[i], chunks[i].data(), chunks[i].size());
+  std::shared_ptr<uint8_t> staging = ctx.pinned->acquire(total);
+  for (size_t i = 0; i < chunks.size(); ++i) memcpy(staging.get() + offs[i], chunks[i].data(), chunks[i].size());
 
-  nbl_options o{sizeof(nbl_options), opts.useVarintRowCount ? 1u : 0u};
+  nbl_options o{sizeof(nbl_options), opts.useVarintRowCount ? 1u : 0u, 0u};
   PlanHolder plan;
-  check(nbl_plan_batch(staging.data(), offs.data(), sizes.data(), (uint32_t)chunks.size(), &o, &plan.p));
+  check(nbl_plan_batch(staging.get(), offs.data(), sizes.data(), (uint32_t)chunks.size(), &o, &plan.p));
   nbl_plan_info info;
   check(nbl_plan_get_info(plan.p, &info));
 
-  std::vector<uint8_t> hostOut(info.out_bytes);
+  std::shared_ptr<uint8_t> hostOut = ctx.pinned->acquire(info.out_bytes);
   {
     std::lock_guard<std::mutex> lock(ctx.mu);
     ctx.ensure();
     ctx.arena.reserve(info.arena_bytes);
     ctx.out.reserve(info.out_bytes);
     ctx.work.reserve(info.work_bytes);
-    hipCheck(hipMemcpyAsync(ctx.arena.ptr, staging.data(), staging.size(), hipMemcpyHostToDevice, ctx.stream_), "H2D");
+    hipCheck(hipMemcpyAsync(ctx.arena.ptr, staging.get(), total, hipMemcpyHostToDevice, ctx.stream_), "H2D");
     check(nbl_plan_upload(plan.p, ctx.work.ptr, ctx.stream_));
     check(nbl_decode_batch_device(plan.p, ctx.arena.ptr, ctx.out.ptr, ctx.work.ptr, ctx.stream_));
-    hipCheck(hipMemcpyAsync(hostOut.data(), ctx.out.ptr, info.out_bytes, hipMemcpyDeviceToHost, ctx.stream_), "D2H");
+    hipCheck(hipMemcpyAsync(hostOut.get(), ctx.out.ptr, info.out_bytes, hipMemcpyDeviceToHost, ctx.stream_), "D2H");
     check(nbl_decode_status(plan.p, ctx.work.ptr, ctx.stream_));  // synchronises the stream
   }
   result.reserve(chunks.size());
   for (uint32_t c = 0; c < chunks.size(); ++c) {
     nbl_chunk_layout lay;
     check(nbl_plan_get_chunk_layout(plan.p, c, &lay));
-    result.push_back(std::make_unique<GpuEncoding>(lay, hostOut.data(), sbf));
+    result.push_back(std::make_unique<GpuEncoding>(lay, hostOut, sbf));
   }
   return result;
 }
