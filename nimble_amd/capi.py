@@ -85,6 +85,11 @@ def lib():
         if not os.path.exists(path):
             raise ImportError(
                 f"{path} is missing: run `python -m nimble_amd.build` (the decoder has no CPU fallback)")
+        # PyTorch bundles its own HIP runtime; it must be the one already in the
+        # process when this library resolves libamdhip64, or the process ends up
+        # with two runtimes and ours sees no device.
+        import torch  # noqa: F401
+
         L = C.CDLL(path)
         vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
         L.nbl_last_error.restype = C.c_char_p
