@@ -60,6 +60,9 @@ typedef struct nbl_options {
  * name their own operation.  With this flag each (level, operation) pair is a
  * launch of its own, so that a profiler attributes time to operations. */
 #define NBL_PLAN_PER_KERNEL_LAUNCHES 1u
+/* Also emit the alphabet (and the raw indices) of dictionary-encoded chunks,
+ * so that a reader can hand out dictionary vectors without expanding them. */
+#define NBL_PLAN_KEEP_DICTIONARY 2u
 
 typedef struct nbl_plan nbl_plan;
 
@@ -100,6 +103,17 @@ typedef struct nbl_chunk_layout {
    * from stringBufferFactory. */
   uint64_t string_offset;
   uint64_t string_bytes;
+  /* NBL_PLAN_KEEP_DICTIONARY only, when the chunk is Dictionary or
+   * Nullable{Dictionary} (Encoding::dictionaryEnabled(), Encoding.h:277-311):
+   * the alphabet, physicalType[dict_size] (string: {offset,length} views like
+   * the values), and -- for a top-level Dictionary -- the raw indices
+   * uint32[rows] that Encoding::materializeIndices yields
+   * (DictionaryEncoding.h:81-83).  has_dictionary is 0 otherwise. */
+  uint32_t has_dictionary;
+  uint32_t dict_size;
+  uint64_t dict_alphabet_offset;
+  uint64_t dict_indices_offset;   /* valid when dict_indices_rows != 0 */
+  uint64_t dict_indices_rows;
 } nbl_chunk_layout;
 
 /*

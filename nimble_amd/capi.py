@@ -33,6 +33,7 @@ class NblOptions(C.Structure):
 
 
 PLAN_PER_KERNEL_LAUNCHES = 1
+PLAN_KEEP_DICTIONARY = 2
 
 
 class NblPlanInfo(C.Structure):
@@ -50,6 +51,8 @@ class NblChunkLayout(C.Structure):
         ("elem_bytes", C.c_uint8), ("non_null_rows", C.c_uint32), ("reserved", C.c_uint32),
         ("values_offset", C.c_uint64), ("values_bytes", C.c_uint64), ("nulls_offset", C.c_uint64),
         ("nulls_bytes", C.c_uint64), ("string_offset", C.c_uint64), ("string_bytes", C.c_uint64),
+        ("has_dictionary", C.c_uint32), ("dict_size", C.c_uint32), ("dict_alphabet_offset", C.c_uint64),
+        ("dict_indices_offset", C.c_uint64), ("dict_indices_rows", C.c_uint64),
     ]
 
 

@@ -522,7 +522,10 @@ __device__ __forceinline__ void body_materialize_raw(const KArgs& a, const NodeD
   const uint64_t rows = nd.rows;
   const uint64_t start = (uint64_t)tile * TE;
   const T base = nd.c0.kind == COL_FBW ? (T)nd.c0.base : (T)0;
-  const uint8_t* src = a.arena + nd.c0.off + start * ES;
+  // the source is a payload in the arena, or an already materialised column
+  // (those start 16-byte aligned and take the aligned branch below)
+  const uint8_t* src = (nd.c0.kind == COL_MAT_WORK ? a.work : nd.c0.kind == COL_MAT_OUT ? (const uint8_t*)a.out : a.arena) +
+                       nd.c0.off + start * ES;
   T* dst = reinterpret_cast<T*>(self_ptr(nd, a)) + start;
   const uint32_t tile_rows = rows - start < TE ? (uint32_t)(rows - start) : TE;
   Vec16<ES> x[4];

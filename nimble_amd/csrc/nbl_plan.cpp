@@ -133,6 +133,7 @@ struct nbl_plan {
   std::vector<Step> steps;
   std::vector<Launch> launches;
   std::vector<TileRef> tiles;
+  bool keep_dictionary = false;  // also emit alphabet + indices of dictionary chunks
   bool fused = true;          // one launch per cascade level (default) or one per (level, kernel, element size)
   int cur_chunk = -1;         // chunk being planned
   std::vector<uint8_t> blob;  // NodeDesc[] | TileRef[] image uploaded to work
@@ -172,6 +173,8 @@ struct nbl_plan {
     d.total_idx = n_totals; n_totals += 2;
   }
   uint64_t string_copy(int level, uint64_t arena_off, uint64_t bytes);
+  uint64_t column_to_out(const ColRef& src, uint32_t rows, uint32_t es, int level);
+  void keep_dictionary_of(int dict_node, bool with_indices);
   void place(int idx, bool root, const ColRef* root_dst);
   void plan_chunk(uint32_t c, uint64_t off, uint64_t size);
   void spread_free_steps(int last_level);
@@ -195,7 +198,8 @@ bool is_u32_index_type(uint8_t dt) { return dt == DT_UINT32 || dt == DT_INT32; }
 uint32_t leaf_kernel(const ColRef& ref, uint32_t es) {
   const uint32_t w = ref.width;
   const bool window = w >= 1 && (es == 8 ? w <= 63 : es == 4 ? w <= 31 : es == 2 ? w <= 15 : w <= 7);
-  if (ref.kind == COL_RAW || (ref.kind == COL_FBW && w == 8 * es)) return K_MATERIALIZE_RAW;
+  if (ref.kind == COL_RAW || ref.kind == COL_MAT_WORK || ref.kind == COL_MAT_OUT || (ref.kind == COL_FBW && w == 8 * es))
+    return K_MATERIALIZE_RAW;
   if (ref.kind == COL_FBW && window) return K_MATERIALIZE_FBW;
   return K_MATERIALIZE;
 }
@@ -421,6 +425,36 @@ uint64_t nbl_plan::string_copy(int level, uint64_t arena_off, uint64_t bytes) {
   return rel;
 }
 
+// Schedules a copy of the column `src` (any kind) into a fresh region of `out`;
+// returns the region's offset.
+uint64_t nbl_plan::column_to_out(const ColRef& src, uint32_t rows, uint32_t es, int level) {
+  const uint64_t off = alloc_out((uint64_t)rows * es);
+  if (rows == 0) return off;
+  NodeDesc d{};
+  d.self.kind = COL_MAT_OUT; d.self.off = off; d.self.rows = rows; d.self.es = (uint8_t)es;
+  d.c0 = src; d.c0.rows = rows; d.rows = rows;
+  const uint32_t dn = add_dnode(d);
+  add_step(level, leaf_kernel(src, es), es, dn, div_up32(rows, kTileBytes / es));
+  decoded_bytes += (uint64_t)rows * es;
+  return off;
+}
+
+// NBL_PLAN_KEEP_DICTIONARY: alphabet (and raw indices) of the placed Dictionary
+// node `dict_node` of the current chunk go to `out` as well.
+void nbl_plan::keep_dictionary_of(int dict_node, bool with_indices) {
+  const PNode& dn = nodes[(size_t)dict_node];
+  const PNode& alpha = nodes[(size_t)dn.child[0]];
+  const PNode& ind = nodes[(size_t)dn.child[1]];
+  nbl_chunk_layout& L = layouts[(size_t)dn.chunk];
+  L.has_dictionary = 1;
+  L.dict_size = alpha.rows;
+  L.dict_alphabet_offset = column_to_out(alpha.ref, alpha.rows, dn.es, alpha.ready);
+  if (with_indices) {
+    L.dict_indices_rows = dn.rows;
+    L.dict_indices_offset = column_to_out(ind.ref, dn.rows, 4, ind.ready);
+  }
+}
+
 // Decides how node `idx` is produced and schedules its kernels.  `root_dst`
 // (roots only) is where the values go in `out`.
 void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
@@ -612,6 +646,10 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       fail(NBL_ERR_UNSUPPORTED, "EncodingType %d is not decoded on the GPU", (int)nn.enc);
   }
 
+  if (root && keep_dictionary) {
+    if (nn.enc == ET_DICTIONARY) keep_dictionary_of(idx, /*with_indices=*/true);
+    else if (nn.enc == ET_NULLABLE && nodes[(size_t)nn.child[0]].enc == ET_DICTIONARY) keep_dictionary_of(nn.child[0], false);
+  }
   if (root) {
     PNode& r = nodes[idx];
     if (r.is_bool) {  // bitmap (or constant) -> one byte per row
@@ -847,6 +885,7 @@ nbl_status nbl_plan_batch(const uint8_t* base, const uint64_t* offsets, const ui
     p->base = base;
     p->varint_rows = options && options->struct_size >= 8 && options->use_varint_row_count;
     p->fused = !(options && options->struct_size >= 12 && (options->flags & NBL_PLAN_PER_KERNEL_LAUNCHES));
+    p->keep_dictionary = options && options->struct_size >= 12 && (options->flags & NBL_PLAN_KEEP_DICTIONARY);
     p->layouts.resize(n_chunks);
     for (uint32_t c = 0; c < n_chunks; ++c) p->span = std::max(p->span, offsets[c] + sizes[c]);
     p->nodes.reserve((size_t)n_chunks * 6);

@@ -31,7 +31,8 @@ class ChunkResult:
 class Plan:
     """nbl_plan_batch over chunks stored in one host buffer."""
 
-    def __init__(self, buffer, chunks: Sequence[tuple[int, int]], varint_rows: bool = False, per_kernel: bool = False):
+    def __init__(self, buffer, chunks: Sequence[tuple[int, int]], varint_rows: bool = False, per_kernel: bool = False,
+                 keep_dictionary: bool = False):
         """per_kernel: one launch per (level, operation) instead of one fused
         launch per cascade level -- for profiling, same results."""
         self.buffer = capi.as_u8(buffer)
@@ -43,7 +44,8 @@ class Plan:
             if o + s > self.buffer.size:
                 raise ValueError("chunk outside the buffer")
         opts = capi.NblOptions(C.sizeof(capi.NblOptions), int(varint_rows),
-                               capi.PLAN_PER_KERNEL_LAUNCHES if per_kernel else 0)
+                               (capi.PLAN_PER_KERNEL_LAUNCHES if per_kernel else 0) |
+                               (capi.PLAN_KEEP_DICTIONARY if keep_dictionary else 0))
         handle = C.c_void_p()
         capi.check(capi.lib().nbl_plan_batch(self.buffer.ctypes.data, offs.ctypes.data, sizes.ctypes.data, n,
                                              C.byref(opts), C.byref(handle)))
@@ -58,7 +60,8 @@ class Plan:
             self.layouts.append(lay)
 
     @staticmethod
-    def from_encodings(encodings: Sequence[bytes], varint_rows: bool = False, per_kernel: bool = False) -> "Plan":
+    def from_encodings(encodings: Sequence[bytes], varint_rows: bool = False, per_kernel: bool = False,
+                       keep_dictionary: bool = False) -> "Plan":
         """Concatenates standalone encodings (16-byte aligned starts are NOT
         required; they are packed back to back on purpose)."""
         offs, pos = [], 0
@@ -66,7 +69,7 @@ class Plan:
             offs.append((pos, len(e)))
             pos += len(e)
         buf = np.frombuffer(b"".join(bytes(e) for e in encodings), dtype=np.uint8) if encodings else np.zeros(0, np.uint8)
-        return Plan(buf, offs, varint_rows, per_kernel)
+        return Plan(buf, offs, varint_rows, per_kernel, keep_dictionary)
 
     def launches(self):
         """[(kernel, elem_bytes, n_tiles, level, alg_bytes)] in launch order."""

@@ -208,6 +208,38 @@ class GpuEncoding final : public Encoding {
         if (off + len > lay.string_bytes) throw NimbleError(NBL_ERR_DEVICE_DATA, "string view outside the string buffer");
       }
     }
+    if (lay.has_dictionary) {
+      dictAlphabet_ = hostOut + lay.dict_alphabet_offset;
+      dictIndices_ = lay.dict_indices_rows ? reinterpret_cast<const uint32_t*>(hostOut + lay.dict_indices_offset) : nullptr;
+      if (lay.data_type == (uint8_t)DataType::String) {  // dictionaryEntries() hands out std::string_view[]
+        const uint64_t* views = reinterpret_cast<const uint64_t*>(dictAlphabet_);
+        dictStrings_.reserve(lay.dict_size);
+        for (uint32_t i = 0; i < lay.dict_size; ++i) {
+          const uint64_t off = views[i] & 0xFFFFFFFFull, len = views[i] >> 32;
+          if (off + len > lay.string_bytes) throw NimbleError(NBL_ERR_DEVICE_DATA, "string view outside the string buffer");
+          dictStrings_.emplace_back(strings_ + off, static_cast<size_t>(len));
+        }
+      }
+    }
+  }
+  bool dictionaryEnabled() const override { return lay_.has_dictionary != 0; }
+  uint32_t dictionarySize() const override {
+    if (!lay_.has_dictionary) return Encoding::dictionarySize();
+    return lay_.dict_size;
+  }
+  const void* dictionaryEntries() const override {
+    if (!lay_.has_dictionary) return Encoding::dictionaryEntries();
+    return lay_.data_type == (uint8_t)DataType::String ? static_cast<const void*>(dictStrings_.data()) : dictAlphabet_;
+  }
+  const void* dictionaryEntry(uint32_t index) const override {
+    if (!lay_.has_dictionary || index >= lay_.dict_size) return Encoding::dictionaryEntry(index);
+    if (lay_.data_type == (uint8_t)DataType::String) return &dictStrings_[index];
+    return dictAlphabet_ + (size_t)index * es_;
+  }
+  void materializeIndices(uint32_t n, uint32_t* buffer) override {
+    if (!dictIndices_) return Encoding::materializeIndices(n, buffer);
+    const uint32_t r = advance(n);
+    memcpy(buffer, dictIndices_ + r, (size_t)n * sizeof(uint32_t));
   }
   EncodingType encodingType() const override { return static_cast<EncodingType>(lay_.encoding_type); }
   DataType dataType() const override { return static_cast<DataType>(lay_.data_type); }
@@ -310,6 +342,9 @@ class GpuEncoding final : public Encoding {
   const uint8_t* values_ = nullptr;
   const uint8_t* nulls_ = nullptr;
   const char* strings_ = nullptr;
+  const uint8_t* dictAlphabet_ = nullptr;
+  const uint32_t* dictIndices_ = nullptr;
+  std::vector<std::string_view> dictStrings_;
 };
 
 struct PlanHolder {
@@ -334,7 +369,7 @@ std::vector<std::unique_ptr<Encoding>> decodeChunks(GpuContext& ctx, const std::
   std::shared_ptr<uint8_t> staging = ctx.pinned->acquire(total);
   for (size_t i = 0; i < chunks.size(); ++i) memcpy(staging.get() + offs[i], chunks[i].data(), chunks[i].size());
 
-  nbl_options o{sizeof(nbl_options), opts.useVarintRowCount ? 1u : 0u, 0u};
+  nbl_options o{sizeof(nbl_options), opts.useVarintRowCount ? 1u : 0u, opts.keepDictionary ? NBL_PLAN_KEEP_DICTIONARY : 0u};
   PlanHolder plan;
   check(nbl_plan_batch(staging.get(), offs.data(), sizes.data(), (uint32_t)chunks.size(), &o, &plan.p));
   nbl_plan_info info;

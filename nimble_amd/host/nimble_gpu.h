@@ -62,6 +62,10 @@ enum class DataType : uint8_t {
 // Encoding::Options fields that matter on the decode side (Encoding.h:115-175).
 struct Options {
   bool useVarintRowCount = false;
+  // Not a reference option: also fetch the alphabet and raw indices of
+  // dictionary-encoded chunks, which turns on the dictionary API below
+  // (costs 4 more bytes per row over the link).
+  bool keepDictionary = false;
 };
 
 // Same contract as nimble::Encoding: a row cursor over one decoded chunk.
@@ -84,6 +88,19 @@ class Encoding {
   virtual uint32_t materializeNullable(uint32_t rowCount, void* buffer, std::function<void*()> getOutputNulls,
                                        const Bitmap* scatterOutputBitmap = nullptr, uint32_t offset = 0) = 0;
   virtual void materializeBoolsAsBits(uint32_t rowCount, uint64_t* buffer, int begin) = 0;
+  // Dictionary API (Encoding.h:277-311).  True for a Dictionary chunk and for a
+  // Nullable chunk over one (NullableEncoding.h:107-122) when the factory was
+  // asked to keep dictionaries; everything else answers false, which sends a
+  // dictionary-aware reader down its ordinary materialize path.
+  virtual bool dictionaryEnabled() const { return false; }
+  virtual uint32_t dictionarySize() const { throw NimbleError(NBL_ERR_ARGUMENT, "dictionarySize on non-dictionary encoding"); }
+  // contiguous alphabet: physicalType[dictionarySize()], std::string_view[] for strings
+  virtual const void* dictionaryEntries() const { throw NimbleError(NBL_ERR_ARGUMENT, "dictionaryEntries on non-dictionary encoding"); }
+  virtual const void* dictionaryEntry(uint32_t /*index*/) const { throw NimbleError(NBL_ERR_ARGUMENT, "dictionaryEntry on non-dictionary encoding"); }
+  // raw indices of the next rowCount rows; shares the row cursor with materialize (DictionaryEncoding.h:81-83)
+  virtual void materializeIndices(uint32_t /*rowCount*/, uint32_t* /*buffer*/) {
+    throw NimbleError(NBL_ERR_ARGUMENT, "materializeIndices on non-dictionary encoding");
+  }
 };
 
 class GpuContext;  // device, stream and reusable device buffers

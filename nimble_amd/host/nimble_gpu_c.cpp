@@ -53,7 +53,8 @@ void* nblh_factory_create(int use_varint_row_count, int device) {
   guard([&] {
     h = new FactoryHandle();
     Options o;
-    o.useVarintRowCount = use_varint_row_count != 0;
+    o.useVarintRowCount = (use_varint_row_count & 1) != 0;
+    o.keepDictionary = (use_varint_row_count & 2) != 0;  // bit 1 of the flags word
     h->f = std::make_unique<GpuEncodingFactory>(o, device);
   });
   return h;
@@ -117,6 +118,13 @@ void nblh_sv_flatten(const void* sv, uint32_t n, uint32_t* lengths, char* bytes)
   }
 }
 int nblh_sizeof_string_view() { return (int)sizeof(std::string_view); }
+
+// dictionary API
+int nblh_dictionary_enabled(void* e) { return E(e).dictionaryEnabled(); }
+int nblh_dictionary_size(void* e, uint32_t* size) { return guard([&] { *size = E(e).dictionarySize(); }); }
+// *entries receives dictionaryEntries(): physicalType[] or std::string_view[]
+int nblh_dictionary_entries(void* e, const void** entries) { return guard([&] { *entries = E(e).dictionaryEntries(); }); }
+int nblh_materialize_indices(void* e, uint32_t n, uint32_t* buffer) { return guard([&] { E(e).materializeIndices(n, buffer); }); }
 
 // ---- stripe decoder --------------------------------------------------------
 void* nblh_stripe_create(void* factory, const char* const* streams, const uint64_t* sizes, uint32_t n) {

@@ -49,6 +49,11 @@ def lib():
         L.nblh_sv_total.restype = u64
         L.nblh_sv_total.argtypes = [vp, u32]
         L.nblh_sv_flatten.argtypes = [vp, u32, vp, vp]
+        L.nblh_dictionary_enabled.restype = i32
+        L.nblh_dictionary_enabled.argtypes = [vp]
+        L.nblh_dictionary_size.argtypes = [vp, C.POINTER(u32)]
+        L.nblh_dictionary_entries.argtypes = [vp, C.POINTER(vp)]
+        L.nblh_materialize_indices.argtypes = [vp, u32, vp]
         L.nblh_stripe_create.restype = vp
         L.nblh_stripe_create.argtypes = [vp, C.POINTER(C.c_char_p), vp, u32]
         L.nblh_stripe_free.argtypes = [vp]
@@ -69,8 +74,8 @@ def _p(a):
 
 
 class Factory:
-    def __init__(self, varint_rows: bool = False, device: int = 0):
-        self._h = lib().nblh_factory_create(int(varint_rows), device)
+    def __init__(self, varint_rows: bool = False, device: int = 0, keep_dictionary: bool = False):
+        self._h = lib().nblh_factory_create(int(varint_rows) | (2 if keep_dictionary else 0), device)
         if not self._h:
             _chk(-1)
 
@@ -119,6 +124,36 @@ class HostEncoding:
         dt = np.uint8 if self.data_type == W.BOOL else W.physical_dtype(self.data_type)
         out = np.empty(n, dtype=dt)
         _chk(lib().nblh_materialize(self._h, n, _p(out)))
+        return out
+
+    @property
+    def dictionary_enabled(self):
+        return bool(lib().nblh_dictionary_enabled(self._h))
+
+    def dictionary_size(self):
+        n = C.c_uint32(0)
+        _chk(lib().nblh_dictionary_size(self._h, C.byref(n)))
+        return n.value
+
+    def dictionary_entries(self):
+        """Alphabet as an array of the physical type, or (lengths, blob) for strings."""
+        n = self.dictionary_size()
+        p = C.c_void_p()
+        _chk(lib().nblh_dictionary_entries(self._h, C.byref(p)))
+        if self.data_type == W.STRING:
+            total = lib().nblh_sv_total(p, n)
+            lengths = np.zeros(n, dtype=np.uint32)
+            blob = np.zeros(max(int(total), 1), dtype=np.uint8)
+            lib().nblh_sv_flatten(p, n, _p(lengths), _p(blob))
+            return lengths, blob[: int(total)]
+        dt = W.physical_dtype(self.data_type)
+        if n == 0:
+            return np.zeros(0, dtype=dt)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n * np.dtype(dt).itemsize,)).view(dt).copy()
+
+    def materialize_indices(self, n):
+        out = np.empty(n, dtype=np.uint32)
+        _chk(lib().nblh_materialize_indices(self._h, n, _p(out)))
         return out
 
     def materialize_bools_as_bits(self, n, buffer, begin):
