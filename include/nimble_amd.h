@@ -149,6 +149,33 @@ nbl_status nbl_split_stream(const uint8_t* stream, uint64_t size,
                             uint64_t* offsets, uint64_t* sizes,
                             uint32_t capacity, uint32_t* n_chunks);
 
+/* Same, but compressed chunks (CompressionType Zstd = 1, Lz4 = 3) are reported
+ * in compression[i] instead of refused; nbl_uncompress inflates them. */
+nbl_status nbl_split_stream_ex(const uint8_t* stream, uint64_t size,
+                               uint64_t* offsets, uint64_t* sizes, uint8_t* compression,
+                               uint32_t capacity, uint32_t* n_chunks);
+
+/*
+ * Host pre-pass for compressed payloads (Compression::uncompress,
+ * dwio/nimble/compression/Compression.h:72-94; framing u32 uncompressed size +
+ * codec frame, ZstdCompressor.cpp:79-99, Lz4Compressor.cpp:60-75).  The codecs
+ * come from the system's libzstd.so.1 / liblz4.so.1, resolved at first use;
+ * without them these return NBL_ERR_UNSUPPORTED.
+ *
+ * nbl_uncompressed_size / nbl_uncompress: one compressed blob (a whole chunk
+ * as nbl_split_stream_ex reports it, or a leaf payload).
+ * nbl_chunk_inflated_size: size of the chunk once every compressed leaf
+ * payload (Trivial values / bitmap / string blob, FixedBitWidth bits) is
+ * inflated, or 0 when nothing in it is compressed (plan it as it is).
+ * nbl_chunk_inflate: writes that encoding -- byte for byte what the writer
+ * emits with compression off -- into `out`; nbl_plan_batch then takes it.
+ */
+nbl_status nbl_uncompressed_size(uint8_t compression, const uint8_t* data, uint64_t size, uint64_t* out_size);
+nbl_status nbl_uncompress(uint8_t compression, const uint8_t* data, uint64_t size, uint8_t* out, uint64_t capacity);
+nbl_status nbl_chunk_inflated_size(const uint8_t* chunk, uint64_t size, const nbl_options* options, uint64_t* out_size);
+nbl_status nbl_chunk_inflate(const uint8_t* chunk, uint64_t size, const nbl_options* options,
+                             uint8_t* out, uint64_t capacity, uint64_t* out_size);
+
 /* Copies the plan's descriptor tables to the front of `d_work`
  * (info.descriptor_bytes, asynchronous on `stream`).  Must precede
  * nbl_decode_batch_device on the same stream for a given d_work. */

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(LIB_DIR, "libnimble_amd.so")
 HOST_LIB_PATH = os.path.join(LIB_DIR, "libnimble_amd_host.so")
 ARCH = "gfx950"
 
-_DEVICE_SOURCES = ["nbl_kernels.hip", "nbl_plan.cpp"]
+_DEVICE_SOURCES = ["nbl_kernels.hip", "nbl_plan.cpp", "nbl_inflate.cpp"]
 _HEADERS = ["nbl_desc.h", os.path.join("..", "..", "include", "nimble_amd.h")]
 
 
@@ -59,7 +59,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
             relink = True
     if relink or _stale(LIB_PATH, objs):
         cmd = [_hipcc(), f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs + [
-            "-Wl,-rpath,/opt/rocm/lib"]
+            "-ldl", "-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)

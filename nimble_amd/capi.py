@@ -25,6 +25,7 @@ EXPORTED_SYMBOLS = (
     "nbl_split_stream", "nbl_plan_upload", "nbl_decode_batch_device", "nbl_decode_status",
     "nbl_plan_get_launch", "nbl_last_error", "nbl_build_arch",
     "nbl_profile_create", "nbl_profile_free", "nbl_decode_batch_profiled", "nbl_profile_collect",
+    "nbl_split_stream_ex", "nbl_uncompressed_size", "nbl_uncompress", "nbl_chunk_inflated_size", "nbl_chunk_inflate",
 )
 
 
@@ -107,6 +108,16 @@ def lib():
         L.nbl_plan_get_chunk_layout.argtypes = [vp, u32, C.POINTER(NblChunkLayout)]
         L.nbl_split_stream.restype = C.c_int
         L.nbl_split_stream.argtypes = [vp, u64, vp, vp, u32, C.POINTER(u32)]
+        L.nbl_split_stream_ex.restype = C.c_int
+        L.nbl_split_stream_ex.argtypes = [vp, u64, vp, vp, vp, u32, C.POINTER(u32)]
+        L.nbl_uncompressed_size.restype = C.c_int
+        L.nbl_uncompressed_size.argtypes = [C.c_uint8, vp, u64, C.POINTER(u64)]
+        L.nbl_uncompress.restype = C.c_int
+        L.nbl_uncompress.argtypes = [C.c_uint8, vp, u64, vp, u64]
+        L.nbl_chunk_inflated_size.restype = C.c_int
+        L.nbl_chunk_inflated_size.argtypes = [vp, u64, C.POINTER(NblOptions), C.POINTER(u64)]
+        L.nbl_chunk_inflate.restype = C.c_int
+        L.nbl_chunk_inflate.argtypes = [vp, u64, C.POINTER(NblOptions), vp, u64, C.POINTER(u64)]
         L.nbl_plan_upload.restype = C.c_int
         L.nbl_plan_upload.argtypes = [vp, vp, vp]
         L.nbl_decode_batch_device.restype = C.c_int
@@ -155,3 +166,18 @@ def split_stream(stream) -> list[tuple[int, int]]:
     sizes = np.zeros(max(n.value, 1), dtype=np.uint64)
     check(lib().nbl_split_stream(a.ctypes.data, a.size, offs.ctypes.data, sizes.ctypes.data, n.value, C.byref(n)))
     return [(int(offs[i]), int(sizes[i])) for i in range(n.value)]
+
+
+def inflate_chunk(data, varint_rows: bool = False) -> bytes:
+    """The chunk with every compressed leaf payload inflated (nbl_chunk_inflate);
+    returns the input unchanged when nothing in it is compressed."""
+    a = as_u8(data)
+    opts = NblOptions(C.sizeof(NblOptions), int(varint_rows), 0)
+    need = C.c_uint64(0)
+    check(lib().nbl_chunk_inflated_size(a.ctypes.data, a.size, C.byref(opts), C.byref(need)))
+    if need.value == 0:
+        return bytes(data)
+    out = np.empty(need.value, dtype=np.uint8)
+    got = C.c_uint64(0)
+    check(lib().nbl_chunk_inflate(a.ctypes.data, a.size, C.byref(opts), out.ctypes.data, out.size, C.byref(got)))
+    return out[: got.value].tobytes()

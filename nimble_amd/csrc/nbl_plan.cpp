@@ -855,7 +855,26 @@ void nbl_plan::finish() {
 extern "C" {
 
 const char* nbl_last_error(void) { return g_last_error.c_str(); }
+void nbl_set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }  // for the library's other translation units
 const char* nbl_build_arch(void) { return "gfx950"; }
+
+nbl_status nbl_split_stream_ex(const uint8_t* stream, uint64_t size, uint64_t* offsets, uint64_t* sizes, uint8_t* compression,
+                               uint32_t capacity, uint32_t* n_chunks) {
+  if ((!stream && size) || !n_chunks) { g_last_error = "null argument"; return NBL_ERR_ARGUMENT; }
+  uint64_t pos = 0; uint32_t n = 0;
+  while (pos < size) {  // InMemoryChunkedStream::nextChunk, velox/ChunkedStream.cpp:36-72
+    if (size - pos < 5) { g_last_error = "Read beyond end of stream"; return NBL_ERR_CORRUPT; }
+    uint32_t len; memcpy(&len, stream + pos, 4);
+    const uint8_t comp = stream[pos + 4];
+    pos += 5;
+    if (len > size - pos) { g_last_error = "Read beyond end of stream"; return NBL_ERR_CORRUPT; }
+    if (comp != 0 && comp != 1 && comp != 3) { g_last_error = "Unexpected stream compression type: " + std::to_string((int)comp); return NBL_ERR_CORRUPT; }
+    if (n < capacity && offsets && sizes) { offsets[n] = pos; sizes[n] = len; if (compression) compression[n] = comp; }
+    ++n; pos += len;
+  }
+  *n_chunks = n;
+  return NBL_OK;
+}
 
 nbl_status nbl_split_stream(const uint8_t* stream, uint64_t size, uint64_t* offsets, uint64_t* sizes,
                             uint32_t capacity, uint32_t* n_chunks) {

@@ -99,6 +99,7 @@ Values = Union[np.ndarray, StringColumn]
 @dataclass
 class Trivial:
     lengths: object = None  # string only: encoding of the uint32 lengths
+    compression: Optional[str] = None  # "zstd" | "lz4": compress the payload (values / bitmap / string blob)
 
 
 @dataclass
@@ -106,6 +107,7 @@ class FixedBitWidth:
     exact_bits: bool = False  # Encoding::Options::fixedBitWidthUseExactBits
     bit_width: Optional[int] = None  # force a width (>= required)
     baseline: Optional[int] = None  # force a baseline (<= min)
+    compression: Optional[str] = None  # "zstd" | "lz4": compress the packed bits
 
 
 @dataclass
@@ -219,6 +221,19 @@ def varint_bytes(values: np.ndarray) -> bytes:
     return out.tobytes()
 
 
+def compress_payload(raw: bytes, compression: Optional[str]):
+    """(CompressionType byte, payload bytes) as Compression::compress frames them:
+    u32 uncompressed size + Zstd frame (compression/ZstdCompressor.cpp:27-59) or
+    raw LZ4 block (Lz4Compressor.cpp).  Needs pyarrow's codecs (test vectors only)."""
+    if compression is None:
+        return W.UNCOMPRESSED, raw
+    import pyarrow as pa
+
+    codec = {"zstd": "zstd", "lz4": "lz4_raw"}[compression]
+    body = pa.Codec(codec).compress(raw, asbytes=True)
+    return {"zstd": 1, "lz4": 3}[compression], struct.pack("<I", len(raw)) + body
+
+
 def _phys(values: np.ndarray, dtype: int) -> np.ndarray:
     """Reinterpret `values` as the unsigned physical type of `dtype`."""
     pt = W.physical_dtype(dtype)
@@ -252,13 +267,12 @@ def encode(spec, values: Values, dtype: int, varint_rows: bool = False) -> bytes
             values = _phys(values, dtype)
 
     if isinstance(spec, Trivial):
-        head = prefix(W.TRIVIAL, dtype, n, vr) + bytes([W.UNCOMPRESSED])
         if dtype == W.STRING:
+            ct, body = compress_payload(values.blob.tobytes(), spec.compression)
             lens = encode(spec.lengths or FixedBitWidth(), values.lengths, W.UINT32, vr)
-            return head + struct.pack("<I", len(lens)) + lens + values.blob.tobytes()
-        if dtype == W.BOOL:
-            return head + _bitmap(values)
-        return head + values.tobytes()
+            return prefix(W.TRIVIAL, dtype, n, vr) + bytes([ct]) + struct.pack("<I", len(lens)) + lens + body
+        ct, body = compress_payload(_bitmap(values) if dtype == W.BOOL else values.tobytes(), spec.compression)
+        return prefix(W.TRIVIAL, dtype, n, vr) + bytes([ct]) + body
 
     if isinstance(spec, FixedBitWidth):
         assert W.is_numeric(dtype)
@@ -274,8 +288,9 @@ def encode(spec, values: Values, dtype: int, varint_rows: bool = False) -> bytes
             width = (width + 7) // 8 * 8
         residual = (values - values.dtype.type(base)) if n else values
         pt = W.physical_dtype(dtype)
-        return (prefix(W.FIXED_BIT_WIDTH, dtype, n, vr) + bytes([W.UNCOMPRESSED]) +
-                np.array([base], dtype=pt).tobytes() + bytes([width]) + bitpack(residual, width))
+        ct, body = compress_payload(bitpack(residual, width), spec.compression)
+        return (prefix(W.FIXED_BIT_WIDTH, dtype, n, vr) + bytes([ct]) +
+                np.array([base], dtype=pt).tobytes() + bytes([width]) + body)
 
     if isinstance(spec, Varint):
         assert W.elem_bytes(dtype) in (4, 8) and W.is_numeric(dtype)
@@ -439,8 +454,13 @@ def _string_ids(col: StringColumn) -> np.ndarray:
 # --------------------------------------------------------------------------
 # chunk / stream framing
 # --------------------------------------------------------------------------
-def chunk(encoding_bytes: bytes, compression: int = W.UNCOMPRESSED) -> bytes:
-    """u32 length | u8 CompressionType | payload (ChunkHeader.h:43-47)."""
+def chunk(encoding_bytes: bytes, compression=W.UNCOMPRESSED) -> bytes:
+    """u32 length | u8 CompressionType | payload (ChunkHeader.h:43-47).  `compression`
+    "zstd" / "lz4" compresses the whole chunk (velox/ChunkedStream.cpp:36-72); an
+    integer only labels the header."""
+    if isinstance(compression, str):
+        ct, body = compress_payload(encoding_bytes, compression)
+        return struct.pack("<IB", len(body), ct) + body
     return struct.pack("<IB", len(encoding_bytes), compression) + encoding_bytes
 
 

@@ -5,7 +5,10 @@
 
 #include <algorithm>
 #include <cstring>
+#include <atomic>
+#include <exception>
 #include <mutex>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -347,6 +350,33 @@ class GpuEncoding final : public Encoding {
   std::vector<std::string_view> dictStrings_;
 };
 
+// fn(i) for i in [0, n) on a few threads when there is enough to move; an
+// exception of any worker is rethrown on the caller
+template <typename F>
+void parallelFor(size_t n, uint64_t bytes, F&& fn) {
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const size_t workers = std::min<size_t>({n, (size_t)std::min(hw, 16u), (size_t)(bytes >> 22) + 1});  // >= 4 MiB per worker
+  if (workers <= 1) {
+    for (size_t i = 0; i < n; ++i) fn(i);
+    return;
+  }
+  std::atomic<size_t> next{0};
+  std::exception_ptr error;
+  std::mutex errorMu;
+  std::vector<std::thread> pool;
+  for (size_t w = 0; w < workers; ++w)
+    pool.emplace_back([&] {
+      try {
+        for (size_t i = next++; i < n; i = next++) fn(i);
+      } catch (...) {
+        std::lock_guard<std::mutex> lock(errorMu);
+        if (!error) error = std::current_exception();
+      }
+    });
+  for (auto& t : pool) t.join();
+  if (error) std::rethrow_exception(error);
+}
+
 struct PlanHolder {
   nbl_plan* p = nullptr;
   ~PlanHolder() { nbl_plan_free(p); }
@@ -358,18 +388,31 @@ std::vector<std::unique_ptr<Encoding>> decodeChunks(GpuContext& ctx, const std::
   std::vector<std::unique_ptr<Encoding>> result;
   if (chunks.empty()) return result;
   // the chunks are packed (16-byte aligned starts) into one pinned staging block:
-  // the image the device arena receives
+  // the image the device arena receives.  Chunks with Zstd / LZ4 leaf payloads
+  // (the reference writer's default) are inflated straight into it.
+  nbl_options o{sizeof(nbl_options), opts.useVarintRowCount ? 1u : 0u, opts.keepDictionary ? NBL_PLAN_KEEP_DICTIONARY : 0u};
   std::vector<uint64_t> offs(chunks.size()), sizes(chunks.size());
+  std::vector<uint8_t> inflate(chunks.size(), 0);
   uint64_t total = 0;
   for (size_t i = 0; i < chunks.size(); ++i) {
+    uint64_t inflated = 0;
+    check(nbl_chunk_inflated_size(reinterpret_cast<const uint8_t*>(chunks[i].data()), chunks[i].size(), &o, &inflated));
+    inflate[i] = inflated != 0;
     offs[i] = total;
-    sizes[i] = chunks[i].size();
-    total += (chunks[i].size() + 15) & ~uint64_t(15);
+    sizes[i] = inflated ? inflated : chunks[i].size();
+    total += (sizes[i] + 15) & ~uint64_t(15);
   }
   std::shared_ptr<uint8_t> staging = ctx.pinned->acquire(total);
-  for (size_t i = 0; i < chunks.size(); ++i) memcpy(staging.get() + offs[i], chunks[i].data(), chunks[i].size());
+  parallelFor(chunks.size(), total, [&](size_t i) {
+    if (inflate[i]) {
+      uint64_t written = 0;
+      check(nbl_chunk_inflate(reinterpret_cast<const uint8_t*>(chunks[i].data()), chunks[i].size(), &o, staging.get() + offs[i],
+                              sizes[i], &written));
+    } else {
+      memcpy(staging.get() + offs[i], chunks[i].data(), chunks[i].size());
+    }
+  });
 
-  nbl_options o{sizeof(nbl_options), opts.useVarintRowCount ? 1u : 0u, opts.keepDictionary ? NBL_PLAN_KEEP_DICTIONARY : 0u};
   PlanHolder plan;
   check(nbl_plan_batch(staging.get(), offs.data(), sizes.data(), (uint32_t)chunks.size(), &o, &plan.p));
   nbl_plan_info info;
@@ -517,14 +560,24 @@ GpuStripeDecoder::GpuStripeDecoder(const GpuEncodingFactory& factory, const std:
     : impl_(std::make_unique<Impl>()) {
   std::vector<std::string_view> chunks;
   std::vector<size_t> owner;
+  std::vector<std::unique_ptr<char[]>> uncompressed;  // chunks whose header names Zstd / LZ4 (ChunkedStream.cpp:49-61)
   for (size_t s = 0; s < streams.size(); ++s) {
     uint32_t n = 0;
     const auto* p = reinterpret_cast<const uint8_t*>(streams[s].data());
-    check(nbl_split_stream(p, streams[s].size(), nullptr, nullptr, 0, &n));
+    check(nbl_split_stream_ex(p, streams[s].size(), nullptr, nullptr, nullptr, 0, &n));
     std::vector<uint64_t> offs(n ? n : 1), sizes(n ? n : 1);
-    check(nbl_split_stream(p, streams[s].size(), offs.data(), sizes.data(), n, &n));
+    std::vector<uint8_t> comp(n ? n : 1);
+    check(nbl_split_stream_ex(p, streams[s].size(), offs.data(), sizes.data(), comp.data(), n, &n));
     for (uint32_t i = 0; i < n; ++i) {
-      chunks.emplace_back(streams[s].data() + offs[i], sizes[i]);
+      if (comp[i] == 0) {
+        chunks.emplace_back(streams[s].data() + offs[i], sizes[i]);
+      } else {
+        uint64_t usize = 0;
+        check(nbl_uncompressed_size(comp[i], p + offs[i], sizes[i], &usize));
+        uncompressed.push_back(std::make_unique<char[]>(usize ? usize : 1));
+        check(nbl_uncompress(comp[i], p + offs[i], sizes[i], reinterpret_cast<uint8_t*>(uncompressed.back().get()), usize));
+        chunks.emplace_back(uncompressed.back().get(), usize);
+      }
       owner.push_back(s);
     }
     impl_->streams.push_back(std::make_unique<GpuStreamDecoder>());

@@ -195,3 +195,31 @@ def test_stripe_decoder_strings(factory):
     host_shim.lib().nblh_sv_flatten(sv.ctypes.data, total, lengths.ctypes.data, blob.ctypes.data)
     assert np.array_equal(lengths, np.concatenate([c.lengths for c in cols]))
     assert np.array_equal(blob[:int(n_bytes)], np.concatenate([c.blob for c in cols]))
+
+
+def test_compressed_leaves_and_chunks_decode_like_their_uncompressed_twins(factory):
+    """The reference writer's default: Zstd (or LZ4) leaf payloads, optionally
+    whole-chunk compression.  The host layer inflates them into the staging
+    buffer; results equal those of the same cascade written uncompressed."""
+    pytest.importorskip("pyarrow")
+    import host_shim
+
+    rng = np.random.default_rng(21)
+    n = 40_000
+    ints = np.repeat(rng.integers(0, 500, n // 8 + 1), 8)[:n].astype(np.int64)
+    strs = random_strings(rng, 30).take(rng.integers(0, 30, n))
+    for codec in ("zstd", "lz4"):
+        e = factory.create(E.encode(E.RLE(lengths=E.FixedBitWidth(compression=codec), values=E.Trivial(compression=codec)), ints, W.INT64))
+        assert np.array_equal(e.materialize(n), ints.view(np.uint64))
+        e = factory.create(E.encode(E.Dictionary(alphabet=E.Trivial(lengths=E.FixedBitWidth(compression=codec), compression=codec),
+                                                 indices=E.FixedBitWidth(compression=codec)), strs, W.STRING))
+        lengths, blob = e.materialize(n)
+        assert np.array_equal(lengths, strs.lengths) and np.array_equal(blob, strs.blob)
+        # stream with a compressed chunk, an uncompressed one and a chunk with compressed leaves
+        a, b, c = ints[:15_000], ints[15_000:30_000], ints[30_000:]
+        stream = (E.chunk(E.encode(E.FixedBitWidth(), a, W.INT64), codec) + E.chunk(E.encode(E.Trivial(), b, W.INT64)) +
+                  E.chunk(E.encode(E.FixedBitWidth(compression=codec), c, W.INT64)))
+        d = host_shim.StripeDecoder(factory, [stream]).stream(0)
+        out = np.zeros(n, dtype=np.uint64)
+        nn, _ = d.next(n, out)
+        assert nn == n and np.array_equal(out, ints.view(np.uint64))
