@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "nimble_gpu.h"
+#include "tablet.h"
 
 using namespace nimble_amd;
 
@@ -160,6 +161,52 @@ int nblh_stripe_skip(void* s, uint32_t stream, uint32_t count) {
 }
 int nblh_stripe_reset(void* s, uint32_t stream) {
   return guard([&] { static_cast<StripeHandle*>(s)->dec->decoder(stream).reset(); });
+}
+
+// ---- tablet (file front-end) ------------------------------------------------
+// `file` must stay alive while the handle is used
+void* nblh_tablet_open(const char* file, uint64_t size) {
+  Tablet* t = nullptr;
+  guard([&] { t = new Tablet(std::string_view(file, size)); });
+  return t;
+}
+void nblh_tablet_free(void* t) { delete static_cast<Tablet*>(t); }
+uint32_t nblh_tablet_stripe_count(void* t) { return static_cast<Tablet*>(t)->stripeCount(); }
+uint64_t nblh_tablet_row_count(void* t) { return static_cast<Tablet*>(t)->rowCount(); }
+int nblh_tablet_stripe_info(void* t, uint32_t stripe, uint32_t* rows, uint64_t* offset, uint32_t* size, uint32_t* streams) {
+  return guard([&] {
+    auto* T = static_cast<Tablet*>(t);
+    *rows = T->stripeRowCount(stripe); *offset = T->stripeOffset(stripe); *size = T->stripeSize(stripe); *streams = T->streamCount(stripe);
+  });
+}
+// (*data, *size) = the stream's bytes inside the file buffer; size 0 when absent
+int nblh_tablet_stream(void* t, uint32_t stripe, uint32_t stream, const char** data, uint64_t* size) {
+  return guard([&] {
+    const std::string_view v = static_cast<Tablet*>(t)->stream(stripe, stream);
+    *data = v.data(); *size = v.size();
+  });
+}
+int nblh_tablet_optional_section(void* t, const char* name, const char** data, uint64_t* size) {
+  return guard([&] {
+    const std::string_view v = static_cast<Tablet*>(t)->optionalSection(name);
+    *data = v.data(); *size = v.size();
+  });
+}
+// all non-empty streams of a stripe decoded in one GPU batch; stream ids (ascending) to ids[0..*n)
+void* nblh_tablet_decode_stripe(void* factory, void* t, uint32_t stripe, uint32_t* ids, uint32_t capacity, uint32_t* n) {
+  StripeHandle* h = new StripeHandle();
+  const int rc = guard([&] {
+    std::vector<std::string_view> views;
+    const auto streams = static_cast<Tablet*>(t)->streams(stripe);
+    *n = (uint32_t)streams.size();
+    for (size_t i = 0; i < streams.size(); ++i) {
+      if (i < capacity) ids[i] = streams[i].first;
+      views.push_back(streams[i].second);
+    }
+    h->dec = std::make_unique<GpuStripeDecoder>(*static_cast<FactoryHandle*>(factory)->f, views);
+  });
+  if (rc != 0) { delete h; return nullptr; }
+  return h;
 }
 
 }  // extern "C"

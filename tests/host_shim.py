@@ -60,6 +60,19 @@ def lib():
         L.nblh_stripe_next.argtypes = [vp, u32, u32, vp, vp, C.POINTER(i32), vp, u32, C.POINTER(u32), C.POINTER(u32)]
         L.nblh_stripe_skip.argtypes = [vp, u32, u32]
         L.nblh_stripe_reset.argtypes = [vp, u32]
+        u64p = C.POINTER(u64)
+        L.nblh_tablet_open.restype = vp
+        L.nblh_tablet_open.argtypes = [vp, u64]
+        L.nblh_tablet_free.argtypes = [vp]
+        L.nblh_tablet_stripe_count.restype = u32
+        L.nblh_tablet_stripe_count.argtypes = [vp]
+        L.nblh_tablet_row_count.restype = u64
+        L.nblh_tablet_row_count.argtypes = [vp]
+        L.nblh_tablet_stripe_info.argtypes = [vp, u32, C.POINTER(u32), u64p, C.POINTER(u32), C.POINTER(u32)]
+        L.nblh_tablet_stream.argtypes = [vp, u32, u32, C.POINTER(vp), u64p]
+        L.nblh_tablet_optional_section.argtypes = [vp, C.c_char_p, C.POINTER(vp), u64p]
+        L.nblh_tablet_decode_stripe.restype = vp
+        L.nblh_tablet_decode_stripe.argtypes = [vp, vp, u32, vp, u32, C.POINTER(u32)]
         _lib = L
     return _lib
 
@@ -206,3 +219,46 @@ class _StreamView:
                                     scatter_size, C.byref(nn), C.byref(nb_)))
         self.last_string_buffers = nb_.value
         return nn.value, bool(req.value)
+
+
+class Tablet:
+    """nimble_amd::Tablet over file bytes held by this object."""
+
+    def __init__(self, data: bytes):
+        self._data = np.frombuffer(bytes(data), dtype=np.uint8).copy()
+        self._h = lib().nblh_tablet_open(_p(self._data), self._data.size)
+        if not self._h:
+            _chk(-1)
+        self.stripe_count = lib().nblh_tablet_stripe_count(self._h)
+        self.row_count = lib().nblh_tablet_row_count(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().nblh_tablet_free(self._h)
+            self._h = None
+
+    def stripe_info(self, i):
+        rows, off, size, streams = C.c_uint32(), C.c_uint64(), C.c_uint32(), C.c_uint32()
+        _chk(lib().nblh_tablet_stripe_info(self._h, i, C.byref(rows), C.byref(off), C.byref(size), C.byref(streams)))
+        return rows.value, off.value, size.value, streams.value
+
+    def stream(self, stripe, stream_id) -> bytes:
+        p, n = C.c_void_p(), C.c_uint64()
+        _chk(lib().nblh_tablet_stream(self._h, stripe, stream_id, C.byref(p), C.byref(n)))
+        return C.string_at(p, n.value) if n.value else b""
+
+    def optional_section(self, name: str) -> bytes:
+        p, n = C.c_void_p(), C.c_uint64()
+        _chk(lib().nblh_tablet_optional_section(self._h, name.encode(), C.byref(p), C.byref(n)))
+        return C.string_at(p, n.value) if n.value else b""
+
+    def decode_stripe(self, factory: "Factory", stripe):
+        """(StripeDecoder-like object, stream ids) for all non-empty streams of the stripe."""
+        ids = np.zeros(max(self.stripe_info(stripe)[3], 1), dtype=np.uint32)
+        n = C.c_uint32()
+        h = lib().nblh_tablet_decode_stripe(factory._h, self._h, stripe, _p(ids), ids.size, C.byref(n))
+        if not h:
+            _chk(-1)
+        sd = StripeDecoder.__new__(StripeDecoder)
+        sd._factory, sd._streams, sd._h, sd._keep = factory, [], h, self
+        return sd, ids[: n.value].tolist()

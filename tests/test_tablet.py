@@ -1,0 +1,102 @@
+"""File front-end: a Nimble file (postscript + FlatBuffers footer / stripes /
+stripe groups, tablet/Footer.fbs) is parsed into per-stripe stream ranges, and a
+stripe read from it decodes on the GPU like its streams do on the oracle."""
+import numpy as np
+import pytest
+
+from nimble_amd import encoder as E
+from nimble_amd import wire as W
+
+from tablet_writer import write_tablet
+
+
+def _file(rng, n_stripes=5, rows=3000):
+    """Three columns: int64 RLE (two chunks per stripe), nullable int32, strings; stream 2 left empty."""
+    stripes, expect = [], []
+    for s in range(n_stripes):
+        n = rows + 17 * s
+        a = np.repeat(rng.integers(0, 40, n // 6 + 1), 6)[:n].astype(np.int64)
+        mask = rng.random(n) < 0.8
+        b = rng.integers(0, 1 << 20, int(mask.sum())).astype(np.int32)
+        pool = [bytes(rng.integers(97, 123, int(rng.integers(0, 12)), dtype=np.uint8)) for _ in range(9)]
+        c = E.StringColumn.from_list([pool[i] for i in rng.integers(0, 9, n)])
+        streams = [
+            E.stream([E.encode(E.RLE(), a[: n // 2], W.INT64), E.encode(E.FixedBitWidth(), a[n // 2:], W.INT64)]),
+            E.stream([E.encode_nullable(E.Nullable(data=E.FixedBitWidth(), nulls=E.SparseBool()), b, mask, W.INT32)]),
+            b"",
+            E.stream([E.encode(E.Dictionary(), c, W.STRING)]),
+        ]
+        stripes.append((n, streams))
+        expect.append((a, b, mask, c))
+    return write_tablet(stripes, stripes_per_group=2, optional={"columnar.schema": b"schema-bytes"}), stripes, expect
+
+
+def test_tablet_metadata_and_stream_ranges():
+    import host_shim
+
+    rng = np.random.default_rng(4)
+    data, stripes, _ = _file(rng)
+    t = host_shim.Tablet(data)
+    assert t.stripe_count == 5 and t.row_count == sum(n for n, _ in stripes)
+    for i, (n, streams) in enumerate(stripes):
+        rows, off, size, n_streams = t.stripe_info(i)
+        assert rows == n and n_streams == 4 and size == sum(len(s) for s in streams)
+        assert data[off: off + size] == b"".join(streams)
+        for sid, s in enumerate(streams):
+            assert t.stream(i, sid) == s
+        assert t.stream(i, 9) == b""
+    assert t.optional_section("columnar.schema") == b"schema-bytes"
+    assert t.optional_section("columnar.stats") == b""
+
+
+def test_tablet_rejects_damage():
+    import host_shim
+
+    data, _, _ = _file(np.random.default_rng(5), n_stripes=2, rows=200)
+    with pytest.raises(host_shim.HostError, match="Magic number mismatch"):
+        host_shim.Tablet(data[:-1] + b"\x00")
+    with pytest.raises(host_shim.HostError, match="postscript"):
+        host_shim.Tablet(data[-10:])
+    bad = bytearray(data)
+    bad[-20:-16] = (len(data) * 2).to_bytes(4, "little")  # footer size larger than the file
+    with pytest.raises(host_shim.HostError, match="footer larger"):
+        host_shim.Tablet(bytes(bad))
+    for pos in range(len(data) - 200, len(data) - 20, 7):  # random damage inside the footer: an error or a parse, never a crash
+        bad = bytearray(data)
+        bad[pos] ^= 0xFF
+        try:
+            host_shim.Tablet(bytes(bad))
+        except host_shim.HostError:
+            pass
+
+
+@pytest.mark.gpu
+def test_stripe_from_file_decodes_on_the_gpu(gpu):
+    import host_shim
+
+    rng = np.random.default_rng(6)
+    data, stripes, expect = _file(rng)
+    t = host_shim.Tablet(data)
+    factory = host_shim.Factory()
+    for i in (0, 3, 4):
+        a, b, mask, c = expect[i]
+        n = stripes[i][0]
+        dec, ids = t.decode_stripe(factory, i)
+        assert ids == [0, 1, 3]
+        out = np.zeros(n, dtype=np.uint64)
+        assert dec.stream(0).next(n, out) == (n, False)
+        assert np.array_equal(out, a.view(np.uint64))
+        out32 = np.zeros(n, dtype=np.uint32)
+        nulls = np.zeros((n + 7) // 8 + 8, dtype=np.uint8)
+        nn, req = dec.stream(1).next(n, out32, nulls)
+        assert nn == int(mask.sum()) and req
+        assert np.array_equal(out32[mask], b.view(np.uint32))
+        assert np.array_equal(np.unpackbits(nulls, bitorder="little")[:n].astype(bool), mask)
+        sv = np.zeros(2 * n, dtype=np.uint64)
+        d2 = dec.stream(2)
+        assert d2.next(n, sv)[0] == n
+        lengths = np.zeros(n, dtype=np.uint32)
+        total = host_shim.lib().nblh_sv_total(sv.ctypes.data, n)
+        blob = np.zeros(max(int(total), 1), dtype=np.uint8)
+        host_shim.lib().nblh_sv_flatten(sv.ctypes.data, n, lengths.ctypes.data, blob.ctypes.data)
+        assert np.array_equal(lengths, c.lengths) and np.array_equal(blob[: int(total)], c.blob)
