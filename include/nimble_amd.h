@@ -217,12 +217,13 @@ nbl_status nbl_plan_get_launch(const nbl_plan* plan, uint32_t launch, nbl_launch
 
 /*
  * Per-launch timing with HIP events recorded on the decode stream (no
- * counterpart in the reference; measurement only).  nbl_profile_create
- * allocates 2 * n_launches * max_steps events; nbl_decode_batch_profiled is
- * nbl_decode_batch_device plus an event before and after every launch of step
- * `step` (< max_steps); nbl_profile_collect synchronises the last event and
- * writes, for every launch, the mean duration in milliseconds over the steps
- * recorded so far.
+ * counterpart in the reference; measurement only).  Consecutive launches of
+ * the same kernel form a group that shares its boundary events, so a step
+ * records (groups + 1) events; a launch's duration is its group's span divided
+ * by the group's launches.  nbl_decode_batch_profiled is
+ * nbl_decode_batch_device plus those events for step `step` (< max_steps);
+ * nbl_profile_collect synchronises the last event and writes, for every
+ * launch, the mean duration in milliseconds over the steps recorded so far.
  */
 typedef struct nbl_profile nbl_profile;
 nbl_status nbl_profile_create(const nbl_plan* plan, uint32_t max_steps, nbl_profile** profile_out);

@@ -982,9 +982,15 @@ nbl_status nbl_plan_upload(nbl_plan* p, void* d_work, void* stream) {
 
 }  // extern "C"
 
+// Consecutive launches of the same kernel form a group and share their boundary
+// events: a step records n_groups + 1 events instead of 2 per launch (an event
+// costs the stream a few microseconds), and a launch's time is its group's span
+// divided by the group's launches (the gaps inside a group are counted in).
 struct nbl_profile {
-  uint32_t n_launches = 0, max_steps = 0, steps_recorded = 0;
-  std::vector<hipEvent_t> events;  // [step][launch][begin,end]
+  uint32_t n_launches = 0, max_steps = 0, steps_recorded = 0, n_groups = 0;
+  std::vector<uint32_t> group_of;    // per launch
+  std::vector<uint32_t> group_size;  // per group
+  std::vector<hipEvent_t> events;    // [step][boundary 0 .. n_groups]
 };
 
 static nbl_status decode_impl(const nbl_plan* p, nbl_profile* prof, uint32_t step, const void* d_arena, void* d_out,
@@ -1001,7 +1007,13 @@ nbl_status nbl_profile_create(const nbl_plan* p, uint32_t max_steps, nbl_profile
   nbl_profile* pr = new nbl_profile();
   pr->n_launches = (uint32_t)p->launches.size();
   pr->max_steps = max_steps;
-  pr->events.resize((size_t)2 * pr->n_launches * max_steps, nullptr);
+  for (size_t l = 0; l < p->launches.size(); ++l) {
+    if (l == 0 || p->launches[l].name != p->launches[l - 1].name) { pr->group_size.push_back(0); }
+    pr->group_of.push_back((uint32_t)pr->group_size.size() - 1);
+    ++pr->group_size.back();
+  }
+  pr->n_groups = (uint32_t)pr->group_size.size();
+  pr->events.resize((size_t)(pr->n_groups + 1) * max_steps, nullptr);
   for (hipEvent_t& e : pr->events) {
     hipError_t rc = hipEventCreate(&e);
     if (rc != hipSuccess) { nbl_profile_free(pr); g_last_error = std::string("hipEventCreate: ") + hipGetErrorString(rc); return NBL_ERR_HIP; }
@@ -1028,14 +1040,16 @@ nbl_status nbl_profile_collect(nbl_profile* pr, float* mean_ms, uint32_t n_launc
   if (!pr || !mean_ms || n_launches != pr->n_launches) { g_last_error = "bad profile argument"; return NBL_ERR_ARGUMENT; }
   for (uint32_t l = 0; l < n_launches; ++l) mean_ms[l] = 0.f;
   if (pr->steps_recorded == 0 || n_launches == 0) return NBL_OK;
-  hipError_t rc = hipEventSynchronize(pr->events[((size_t)(pr->steps_recorded - 1) * n_launches + (n_launches - 1)) * 2 + 1]);
+  const size_t per_step = (size_t)pr->n_groups + 1;
+  hipError_t rc = hipEventSynchronize(pr->events[(size_t)(pr->steps_recorded - 1) * per_step + pr->n_groups]);
   if (rc != hipSuccess) { g_last_error = std::string("hipEventSynchronize: ") + hipGetErrorString(rc); return NBL_ERR_HIP; }
   for (uint32_t s = 0; s < pr->steps_recorded; ++s)
     for (uint32_t l = 0; l < n_launches; ++l) {
+      const uint32_t g = pr->group_of[l];
       float ms = 0.f;
-      rc = hipEventElapsedTime(&ms, pr->events[((size_t)s * n_launches + l) * 2], pr->events[((size_t)s * n_launches + l) * 2 + 1]);
+      rc = hipEventElapsedTime(&ms, pr->events[(size_t)s * per_step + g], pr->events[(size_t)s * per_step + g + 1]);
       if (rc != hipSuccess) { g_last_error = std::string("hipEventElapsedTime: ") + hipGetErrorString(rc); return NBL_ERR_HIP; }
-      mean_ms[l] += ms / (float)pr->steps_recorded;
+      mean_ms[l] += ms / (float)pr->group_size[g] / (float)pr->steps_recorded;
     }
   return NBL_OK;
 }
@@ -1066,9 +1080,11 @@ static nbl_status decode_impl(const nbl_plan* p, nbl_profile* prof, uint32_t ste
     const Launch& L = p->launches[li];
     a.tiles = tiles + L.tile_begin;
     a.n_tiles = L.n_tiles;
-    if (prof) (void)hipEventRecord(prof->events[((size_t)step * nl + li) * 2], static_cast<hipStream_t>(stream));
+    if (prof && (li == 0 || prof->group_of[li] != prof->group_of[li - 1]))
+      (void)hipEventRecord(prof->events[(size_t)step * (prof->n_groups + 1) + prof->group_of[li]], static_cast<hipStream_t>(stream));
     const int rc = nbl_launch_kernel(L.kernel, L.es, &a, stream);
-    if (prof) (void)hipEventRecord(prof->events[((size_t)step * nl + li) * 2 + 1], static_cast<hipStream_t>(stream));
+    if (prof && li + 1 == nl)
+      (void)hipEventRecord(prof->events[(size_t)step * (prof->n_groups + 1) + prof->n_groups], static_cast<hipStream_t>(stream));
     if (rc != 0) {
       g_last_error = "launch of " + L.name + " failed";
       return NBL_ERR_HIP;
