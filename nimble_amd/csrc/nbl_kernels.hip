@@ -248,6 +248,47 @@ __device__ __forceinline__ uint8_t* self_ptr(const NodeDesc& nd, const KArgs& a)
   return (nd.self.kind == COL_MAT_OUT ? a.out : a.work) + nd.self.off;
 }
 
+// Byte-misaligned 16-byte global loads are served at about half the rate of
+// aligned ones once neighbouring lanes are more than two bytes apart, so wide
+// rows are not read with one misaligned window per lane.  Instead the
+// workgroup copies the tile's packed bytes into LDS with aligned, fully
+// coalesced 16-byte loads (every byte fetched once) and each lane assembles
+// its window from five dword-aligned LDS reads.
+//
+// stage_tile: copies [p - mis, p + nbytes + 4) to `stage` (mis = p & 15) and
+// returns mis; the caller synchronises.  ROUNDS * 4096 bytes must cover it.
+template <int ROUNDS>
+__device__ __forceinline__ uint32_t stage_tile(const uint8_t* p, uint32_t nbytes, u32x4* stage) {
+  const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 15u);
+  const u32x4* asrc = reinterpret_cast<const u32x4*>(p - mis);
+  const uint32_t nvec = (mis + nbytes + 4u + 15u) >> 4;  // + 4: the fifth dword of the last window
+  if (nvec <= kBlock) {  // a short range (sparse selections, few runs): one load per thread instead of ROUNDS
+    if (threadIdx.x < nvec) stage[threadIdx.x] = ld16_stream(asrc + threadIdx.x);
+    return mis;
+  }
+  u32x4 g[ROUNDS];
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const uint32_t i = r * kBlock + threadIdx.x;
+    g[r] = ld16_stream(asrc + (i < nvec ? i : nvec - 1));
+  }
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const uint32_t i = r * kBlock + threadIdx.x;
+    if (i < nvec) stage[i] = g[r];
+  }
+  return mis;
+}
+// 128 bits starting `lb` bits into the staged bytes
+__device__ __forceinline__ void lds_window(const uint32_t* s32, uint32_t lb, uint32_t& n0, uint32_t& n1, uint32_t& n2, uint32_t& n3) {
+  const uint32_t d0 = lb >> 5, S = lb & 31u;
+  const uint32_t a = s32[d0], b = s32[d0 + 1], c = s32[d0 + 2], d = s32[d0 + 3], e = s32[d0 + 4];
+  n0 = __builtin_amdgcn_alignbit(b, a, S);
+  n1 = __builtin_amdgcn_alignbit(c, b, S);
+  n2 = __builtin_amdgcn_alignbit(d, c, S);
+  n3 = __builtin_amdgcn_alignbit(e, d, S);
+}
+
 // ------------------------------------------------------------ column readers
 // A Reader fixes, at compile time, HOW a numeric column is read, so that the
 // loops using it are straight-line code: all loads of a tile are issued back
@@ -325,6 +366,45 @@ struct Reader {
       }
     }
   };
+  // Elements [first, first + n) copied as raw bytes into LDS with aligned,
+  // non-temporal 16-byte loads (stage_tile); at(rel) then unpacks element
+  // first + rel from LDS.  The range must fit kTileBytes (see fits()); the
+  // caller synchronises between stage() and at().
+  struct Staged {
+    const Reader& r;
+    const uint32_t* s32;
+    uint32_t bit0;
+    __device__ __forceinline__ T at(uint32_t rel) const {
+      if constexpr (RK == RK_CONST) {
+        return r.base;
+      } else {
+        const uint32_t lb = bit0 + rel * (RK == RK_PTR ? 8u * CES : r.w);
+        const uint32_t d0 = lb >> 5, S = lb & 31u;
+        const uint32_t lo = __builtin_amdgcn_alignbit(s32[d0 + 1], s32[d0], S);
+        if constexpr (RK == RK_PTR) {
+          if constexpr (CES == 8) return (T)((((uint64_t)__builtin_amdgcn_alignbit(s32[d0 + 2], s32[d0 + 1], S) << 32) | lo) + r.base);
+          else return (T)((T)lo + r.base);
+        } else if constexpr (RK == RK_FBW32) {
+          return (T)((T)(lo & (uint32_t)r.mask) + r.base);
+        } else {
+          const uint64_t v = ((uint64_t)__builtin_amdgcn_alignbit(s32[d0 + 2], s32[d0 + 1], S) << 32) | lo;
+          return (T)((T)(v & r.mask) + r.base);
+        }
+      }
+    }
+  };
+  __device__ __forceinline__ uint32_t bits_per_elem() const { return RK == RK_PTR ? 8u * CES : RK == RK_CONST ? 0u : w; }
+  __device__ __forceinline__ bool fits(uint32_t n) const { return (uint64_t)n * bits_per_elem() <= 8ull * kTileBytes; }
+  __device__ __forceinline__ Staged stage(uint64_t first, uint32_t n, uint8_t* lds) const {
+    if constexpr (RK == RK_CONST) {
+      return Staged{*this, reinterpret_cast<const uint32_t*>(lds), 0u};
+    } else {
+      const uint64_t bit = first * bits_per_elem();
+      const uint32_t sh = (uint32_t)bit & 7u;
+      const uint32_t mis = stage_tile<5>(p + (bit >> 3), (sh + n * bits_per_elem() + 7u) >> 3, reinterpret_cast<u32x4*>(lds));
+      return Staged{*this, reinterpret_cast<const uint32_t*>(lds), mis * 8u + sh};
+    }
+  }
   __device__ __forceinline__ View view(uint64_t first) const {
     if constexpr (RK == RK_PTR || RK == RK_CONST) {
       return View{*this, p + first * CES, 0u};
@@ -358,8 +438,11 @@ __device__ __forceinline__ void with_reader(const ColRef& c, const KArgs& a, F&&
 template <int ES>
 constexpr uint32_t kBatch = ES == 8 ? 4 : ES == 4 ? 2 : 1;
 
-// LDS of one workgroup, shared by every body (the fused launch runs them all).
-constexpr uint32_t kSmemBytes = kTileBytes + 2048 + 1024 + 64;
+// LDS of one workgroup, shared by every body (the fused launch runs them all):
+// [0, kStageBytes) staged bytes or values of a tile (16 KiB + alignment slack),
+// then 2 KiB of bitmap words, 1 KiB of prefix counts, 64 bytes of scratch.
+constexpr uint32_t kStageBytes = kTileBytes + 64;
+constexpr uint32_t kSmemBytes = kStageBytes + 2048 + 1024 + 64;
 
 // =========================================================== tile bodies
 // Every body processes ONE tile of one node.  They are instantiated twice: in
@@ -384,43 +467,6 @@ constexpr uint32_t kSmemBytes = kTileBytes + 2048 + 1024 + 64;
 // fit the five dwords a lane reads.
 __host__ __device__ constexpr bool fbw_window_ok(uint32_t es, uint32_t w) {
   return w >= 1 && (es == 8 ? w <= 63 : es == 4 ? w <= 31 : es == 2 ? w <= 15 : w <= 7);
-}
-
-// Byte-misaligned 16-byte global loads are served at about half the rate of
-// aligned ones once neighbouring lanes are more than two bytes apart, so wide
-// rows are not read with one misaligned window per lane.  Instead the
-// workgroup copies the tile's packed bytes into LDS with aligned, fully
-// coalesced 16-byte loads (every byte fetched once) and each lane assembles
-// its window from five dword-aligned LDS reads.
-//
-// stage_tile: copies [p - mis, p + nbytes + 4) to `stage` (mis = p & 15) and
-// returns mis; the caller synchronises.  ROUNDS * 4096 bytes must cover it.
-template <int ROUNDS>
-__device__ __forceinline__ uint32_t stage_tile(const uint8_t* p, uint32_t nbytes, u32x4* stage) {
-  const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 15u);
-  const u32x4* asrc = reinterpret_cast<const u32x4*>(p - mis);
-  const uint32_t nvec = (mis + nbytes + 4u + 15u) >> 4;  // + 4: the fifth dword of the last window
-  u32x4 g[ROUNDS];
-#pragma unroll
-  for (int r = 0; r < ROUNDS; ++r) {
-    const uint32_t i = r * kBlock + threadIdx.x;
-    g[r] = ld16_stream(asrc + (i < nvec ? i : nvec - 1));
-  }
-#pragma unroll
-  for (int r = 0; r < ROUNDS; ++r) {
-    const uint32_t i = r * kBlock + threadIdx.x;
-    if (i < nvec) stage[i] = g[r];
-  }
-  return mis;
-}
-// 128 bits starting `lb` bits into the staged bytes
-__device__ __forceinline__ void lds_window(const uint32_t* s32, uint32_t lb, uint32_t& n0, uint32_t& n1, uint32_t& n2, uint32_t& n3) {
-  const uint32_t d0 = lb >> 5, S = lb & 31u;
-  const uint32_t a = s32[d0], b = s32[d0 + 1], c = s32[d0 + 2], d = s32[d0 + 3], e = s32[d0 + 4];
-  n0 = __builtin_amdgcn_alignbit(b, a, S);
-  n1 = __builtin_amdgcn_alignbit(c, b, S);
-  n2 = __builtin_amdgcn_alignbit(d, c, S);
-  n3 = __builtin_amdgcn_alignbit(e, d, S);
 }
 
 // V values of w bits from the 128-bit window n0..n3 (w < 8*ES), + base
@@ -806,9 +852,9 @@ __device__ __forceinline__ void body_rle_expand(const KArgs& a, const NodeDesc& 
   constexpr uint32_t TE = kTileBytes / ES;
   constexpr uint32_t W = TE / 64;
   T* s_vals = reinterpret_cast<T*>(smem);                                  // TE elements = kTileBytes
-  uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem + kTileBytes);        // W <= 256 words
-  uint32_t* s_pref = reinterpret_cast<uint32_t*>(smem + kTileBytes + 2048);  // W words
-  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + kTileBytes + 3072);     // 4 words
+  uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem + kStageBytes);        // W <= 256 words
+  uint32_t* s_pref = reinterpret_cast<uint32_t*>(smem + kStageBytes + 2048);  // W words
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + kStageBytes + 3072);     // 4 words
   uint32_t* s_k = tmp + 4;                                                   // 2 words
   const uint64_t rows = nd.rows;
   const uint32_t R = nd.c0.rows;
@@ -1037,10 +1083,9 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
   constexpr uint32_t TE = select_tile_rows(ES);
   constexpr uint32_t W = TE / 64;
   static_assert(TE * ES == kTileBytes && W <= kBlock, "tile geometry");
-  T* s_vals = reinterpret_cast<T*>(smem);                                   // the tile's selected values, <= TE
-  uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem + kTileBytes);         // W <= 256 words
-  uint32_t* s_pref = reinterpret_cast<uint32_t*>(smem + kTileBytes + 2048);  // W words
-  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + kTileBytes + 3072);
+  uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem + kStageBytes);         // W <= 256 words
+  uint32_t* s_pref = reinterpret_cast<uint32_t*>(smem + kStageBytes + 2048);  // W words
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + kStageBytes + 3072);
   const uint64_t rows = nd.rows;
   const uint64_t p0 = (uint64_t)tile * TE;
   const uint32_t tile_rows = rows - p0 < TE ? (uint32_t)(rows - p0) : TE;
@@ -1049,10 +1094,9 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
   const uint32_t nvals = nd.c1.rows;
   if (tile == 0 && threadIdx.x == 0 && a.totals[nd.total_idx] != nvals) atomicOr(a.status, ST_SELECT_COUNT);
   // The tile's selected rows take the consecutive ranks [base, next): both come
-  // from the scanned partials, so the values are requested at once, without
-  // waiting for the bitmap.  They are copied to LDS with coalesced loads (each
-  // fetched once); every row then picks its value -- or the fill -- from LDS.
-  // Counts that disagree with the values child (corrupt input) are clamped.
+  // from the scanned partials, so the values can be fetched without waiting for
+  // the bitmap.  Counts that disagree with the values child (corrupt input) are
+  // clamped, never followed.
   const uint32_t base = a.parts[nd.part_base + tile];
   const uint32_t next = tile + 1 < nd.n_parts ? a.parts[nd.part_base + tile + 1] : a.totals[nd.total_idx];
   const uint32_t count = next - base < TE ? next - base : TE;
@@ -1061,98 +1105,58 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
   const uint64_t w = (uint64_t)tile * W + threadIdx.x;
   uint64_t word = 0;
   if (threadIdx.x < W && w * 64 < rows) word = bits_word_masked(nd.sel, a, w, invert);
-  constexpr bool kStage = ES < 8;  // 8-byte rows: two values per lane and round, cheaper fetched directly (below)
-  if (kStage && n) {
-    with_reader<ES>(nd.c1, a, [&](auto rd) {
-      const auto vals = rd.view(base);
-      for (uint32_t j0 = threadIdx.x; j0 < n; j0 += 8 * kBlock) {  // eight loads in flight per thread
-        T t[8];
-#pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) {
-          const uint32_t j = j0 + u * kBlock;
-          t[u] = vals.at(j < n ? j : n - 1);
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < 8; ++u) {
-          const uint32_t j = j0 + u * kBlock;
-          if (j < n) s_vals[j] = t[u];
-        }
-      }
-    });
-  }
-  if ((nd.flags & NF_WRITE_NULLS) && threadIdx.x < W && w * 64 < rows)
-    reinterpret_cast<uint64_t*>(a.out + nd.aux_off)[w] = invert ? ~word & (w * 64 + 64 > rows ? wmask((uint32_t)(rows - w * 64)) : ~0ull) : word;
-  uint32_t total;
-  const uint32_t ex = block_excl_scan((uint32_t)__popcll(word), tmp, total);
-  if (threadIdx.x < W) { s_bits[threadIdx.x] = word; s_pref[threadIdx.x] = ex; }
-  __syncthreads();
   const T fill = (T)nd.aux;
-  const uint32_t last = n ? n - 1 : 0u;
-  if constexpr (!kStage) {
-    if (n == 0) {
-      Vec16<ES> x;
+  auto write_nulls = [&]() {
+    if ((nd.flags & NF_WRITE_NULLS) && threadIdx.x < W && w * 64 < rows)
+      reinterpret_cast<uint64_t*>(a.out + nd.aux_off)[w] = invert ? ~word & (w * 64 + 64 > rows ? wmask((uint32_t)(rows - w * 64)) : ~0ull) : word;
+  };
+  if (n == 0) {  // nothing selected (or nothing to select from): a fill, no ranks needed
+    write_nulls();
+    Vec16<ES> x;
 #pragma unroll
-      for (uint32_t j = 0; j < V; ++j) x.v[j] = fill;
+    for (uint32_t j = 0; j < V; ++j) x.v[j] = fill;
 #pragma unroll
-      for (uint32_t it = 0; it < 4; ++it) {
-        const uint32_t q0 = (it * kBlock + threadIdx.x) * V;
-        if (q0 < tile_rows) store_vec<ES>(dst, q0, tile_rows, x);
-      }
-      return;
+    for (uint32_t it = 0; it < 4; ++it) {
+      const uint32_t q0 = (it * kBlock + threadIdx.x) * V;
+      if (q0 < tile_rows) store_vec<ES>(dst, q0, tile_rows, x);
     }
-    // Selected rows take consecutive ranks, so these per-lane loads are lane
-    // monotone (coalesced).  They are issued unconditionally at a clamped rank
-    // -- a lane whose bit is clear loads its successor's value and drops it --
-    // which keeps all eight loads of the tile in flight at once.
-    with_reader<ES>(nd.c1, a, [&](auto rd) {
-      const auto vals = rd.view(base);
-      T x[4][V];
-      uint32_t bv[4];
+    return;
+  }
+  // The n values are copied as raw bytes into LDS with aligned streaming loads
+  // (each byte fetched once) while the bitmap words are still in flight; every
+  // row then unpacks its value -- or takes the fill -- from LDS at its rank.
+  const uint32_t last = n - 1;
+  with_reader<ES>(nd.c1, a, [&](auto rd) {
+    const auto vals = rd.stage(base, n, smem);
+    write_nulls();
+    uint32_t total;
+    const uint32_t ex = block_excl_scan((uint32_t)__popcll(word), tmp, total);
+    if (threadIdx.x < W) { s_bits[threadIdx.x] = word; s_pref[threadIdx.x] = ex; }
+    __syncthreads();
 #pragma unroll
-      for (uint32_t u = 0; u < 4; ++u) {
-        const uint32_t q0 = (u * kBlock + threadIdx.x) * V;
-        const uint64_t wd = s_bits[q0 >> 6];
-        const uint32_t b = q0 & 63;
-        uint32_t r = s_pref[q0 >> 6] + (uint32_t)__popcll(wd & ((1ull << b) - 1ull));
-        const uint32_t bits = (uint32_t)(wd >> b);
-        bv[u] = bits;
+    for (uint32_t it = 0; it < 4; ++it) {
+      const uint32_t q0 = (it * kBlock + threadIdx.x) * V;
+      if (q0 >= tile_rows) break;
+      const uint64_t wd = s_bits[q0 >> 6];
+      const uint32_t b = q0 & 63;
+      uint32_t r = s_pref[q0 >> 6] + (uint32_t)__popcll(wd & ((1ull << b) - 1ull));
+      const uint32_t bits = (uint32_t)(wd >> b);  // bit j = row q0 + j (b + V <= 64)
+      Vec16<ES> o;
+      if ((bits & ((1u << V) - 1u)) == 0) {  // no selected row in this vector (sparse selections): all fill
+#pragma unroll
+        for (uint32_t j = 0; j < V; ++j) o.v[j] = fill;
+      } else {
+        o.q = make_u32x4(0, 0, 0, 0);
 #pragma unroll
         for (uint32_t j = 0; j < V; ++j) {
-          x[u][j] = vals.at(r < last ? r : last);
+          const T v = vals.at(r < last ? r : last);
+          vec_set<ES>(o, j, ((bits >> j) & 1u) ? v : fill);
           r += (bits >> j) & 1u;
         }
       }
-#pragma unroll
-      for (uint32_t u = 0; u < 4; ++u) {
-        const uint32_t q0 = (u * kBlock + threadIdx.x) * V;
-        if (q0 < tile_rows) {
-          Vec16<ES> o;
-#pragma unroll
-          for (uint32_t j = 0; j < V; ++j) o.v[j] = ((bv[u] >> j) & 1u) ? x[u][j] : fill;
-          store_vec<ES>(dst, q0, tile_rows, o);
-        }
-      }
-    });
-    return;
-  }
-#pragma unroll
-  for (uint32_t it = 0; it < 4; ++it) {
-    const uint32_t q0 = (it * kBlock + threadIdx.x) * V;
-    if (q0 >= tile_rows) break;
-    const uint64_t wd = s_bits[q0 >> 6];
-    const uint32_t b = q0 & 63;
-    uint32_t r = s_pref[q0 >> 6] + (uint32_t)__popcll(wd & ((1ull << b) - 1ull));
-    const uint32_t bits = n ? (uint32_t)(wd >> b) : 0u;  // bit j = row q0 + j (b + V <= 64)
-    Vec16<ES> o;
-    o.q = make_u32x4(0, 0, 0, 0);
-#pragma unroll
-    for (uint32_t j = 0; j < V; ++j) {
-      const T v = s_vals[r < last ? r : last];
-      vec_set<ES>(o, j, ((bits >> j) & 1u) ? v : fill);
-      r += (bits >> j) & 1u;
+      store_vec<ES>(dst, q0, tile_rows, o);
     }
-    store_vec<ES>(dst, q0, tile_rows, o);
-  }
+  });
 }
 
 // Nullable<bool>: scatter a bitmap of values by the selection bitmap.
@@ -1342,7 +1346,7 @@ __device__ __forceinline__ void body_varint_decode(const KArgs& a, const NodeDes
   using T = typename ElemT<ES>::type;
   u32x4* stage = reinterpret_cast<u32x4*>(smem);                        // <= 16 + 4096 + 10 + 15 + 4 bytes
   uint16_t* s_start = reinterpret_cast<uint16_t*>(smem + 8192);          // <= 4096 offsets
-  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + kTileBytes + 3072);
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + kStageBytes + 3072);
   const uint8_t* payload = a.arena + nd.c0.off;
   const uint64_t len = nd.aux2;
   const uint64_t rows = nd.rows;

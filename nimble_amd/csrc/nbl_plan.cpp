@@ -845,7 +845,7 @@ void nbl_plan::finish() {
   for (size_t i = 0; i < dnodes.size(); ++i)
     if (aux_in_work[i]) dnodes[i].aux_off += scratch_base;  // run-end arrays
   work_bytes = scratch_base + cur_work + kAlign;
-  out_bytes = std::max<uint64_t>(cur_out, kAlign);
+  out_bytes = cur_out + kAlign;  // slack: staged 16-byte loads may run a few bytes past a column
   blob.assign(desc_bytes, 0);
   if (!dnodes.empty()) memcpy(blob.data(), dnodes.data(), dnodes.size() * sizeof(NodeDesc));
   if (!tiles.empty()) memcpy(blob.data() + tiles_off, tiles.data(), tiles.size() * sizeof(TileRef));
