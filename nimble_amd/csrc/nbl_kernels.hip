@@ -432,12 +432,6 @@ __device__ __forceinline__ void with_reader(const ColRef& c, const KArgs& a, F&&
   }
 }
 
-// Iterations of a tile's four store rounds whose loads are kept in flight
-// together: eight element loads per thread (sixteen for 1-byte elements), a
-// register budget that keeps every body at eight waves per SIMD.
-template <int ES>
-constexpr uint32_t kBatch = ES == 8 ? 4 : ES == 4 ? 2 : 1;
-
 // LDS of one workgroup, shared by every body (the fused launch runs them all):
 // [0, kStageBytes) staged bytes or values of a tile (16 KiB + alignment slack),
 // then 2 KiB of bitmap words, 1 KiB of prefix counts, 64 bytes of scratch.
@@ -461,13 +455,6 @@ constexpr uint32_t kSmemBytes = kStageBytes + 2048 + 1024 + 64;
 //   materialize_raw : byte-aligned elements (Trivial, or bit width == 8*ES),
 //                     copy + baseline
 //   materialize     : everything else (Constant fill, odd width/type pairs)
-
-// Widths the window variant handles (the planner uses the same predicate):
-// the V = 16/ES values of one output vector, plus up to 31 bits of shift, must
-// fit the five dwords a lane reads.
-__host__ __device__ constexpr bool fbw_window_ok(uint32_t es, uint32_t w) {
-  return w >= 1 && (es == 8 ? w <= 63 : es == 4 ? w <= 31 : es == 2 ? w <= 15 : w <= 7);
-}
 
 // V values of w bits from the 128-bit window n0..n3 (w < 8*ES), + base
 template <int ES>
