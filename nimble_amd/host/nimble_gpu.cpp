@@ -440,6 +440,69 @@ std::vector<std::unique_ptr<Encoding>> decodeChunks(GpuContext& ctx, const std::
   return result;
 }
 
+class DeviceBatchImpl final : public DeviceBatch {
+ public:
+  size_t chunkCount() const override { return layouts.size(); }
+  const nbl_chunk_layout& layout(size_t chunk) const override { return layouts.at(chunk); }
+  const void* data() const override { return out.ptr; }
+  uint64_t bytes() const override { return outBytes; }
+  int device() const override { return ctx->device_; }
+  void* stream() const override { return ctx->stream_; }
+  std::shared_ptr<GpuContext> ctx;
+  DeviceBuffer out;
+  uint64_t outBytes = 0;
+  std::vector<nbl_chunk_layout> layouts;
+};
+
+std::unique_ptr<DeviceBatch> decodeChunksToDevice(const std::shared_ptr<GpuContext>& ctxp, const std::vector<std::string_view>& chunks,
+                                                  const Options& opts) {
+  GpuContext& ctx = *ctxp;
+  auto batch = std::make_unique<DeviceBatchImpl>();
+  batch->ctx = ctxp;
+  if (chunks.empty()) return batch;
+  nbl_options o{sizeof(nbl_options), opts.useVarintRowCount ? 1u : 0u, opts.keepDictionary ? NBL_PLAN_KEEP_DICTIONARY : 0u};
+  std::vector<uint64_t> offs(chunks.size()), sizes(chunks.size());
+  std::vector<uint8_t> inflate(chunks.size(), 0);
+  uint64_t total = 0;
+  for (size_t i = 0; i < chunks.size(); ++i) {
+    uint64_t inflated = 0;
+    check(nbl_chunk_inflated_size(reinterpret_cast<const uint8_t*>(chunks[i].data()), chunks[i].size(), &o, &inflated));
+    inflate[i] = inflated != 0;
+    offs[i] = total;
+    sizes[i] = inflated ? inflated : chunks[i].size();
+    total += (sizes[i] + 15) & ~uint64_t(15);
+  }
+  std::shared_ptr<uint8_t> staging = ctx.pinned->acquire(total);
+  parallelFor(chunks.size(), total, [&](size_t i) {
+    if (inflate[i]) {
+      uint64_t written = 0;
+      check(nbl_chunk_inflate(reinterpret_cast<const uint8_t*>(chunks[i].data()), chunks[i].size(), &o, staging.get() + offs[i],
+                              sizes[i], &written));
+    } else {
+      memcpy(staging.get() + offs[i], chunks[i].data(), chunks[i].size());
+    }
+  });
+  PlanHolder plan;
+  check(nbl_plan_batch(staging.get(), offs.data(), sizes.data(), (uint32_t)chunks.size(), &o, &plan.p));
+  nbl_plan_info info;
+  check(nbl_plan_get_info(plan.p, &info));
+  {
+    std::lock_guard<std::mutex> lock(ctx.mu);
+    ctx.ensure();
+    ctx.arena.reserve(info.arena_bytes);
+    ctx.work.reserve(info.work_bytes);
+    batch->out.reserve(info.out_bytes);   // owned by the batch: it outlives this call
+    batch->outBytes = info.out_bytes;
+    hipCheck(hipMemcpyAsync(ctx.arena.ptr, staging.get(), total, hipMemcpyHostToDevice, ctx.stream_), "H2D");
+    check(nbl_plan_upload(plan.p, ctx.work.ptr, ctx.stream_));
+    check(nbl_decode_batch_device(plan.p, ctx.arena.ptr, batch->out.ptr, ctx.work.ptr, ctx.stream_));
+    check(nbl_decode_status(plan.p, ctx.work.ptr, ctx.stream_));  // synchronises the stream
+  }
+  batch->layouts.resize(chunks.size());
+  for (uint32_t c = 0; c < chunks.size(); ++c) check(nbl_plan_get_chunk_layout(plan.p, c, &batch->layouts[c]));
+  return batch;
+}
+
 }  // namespace
 
 GpuEncodingFactory::GpuEncodingFactory(Options options, int device)
@@ -471,6 +534,10 @@ std::vector<std::unique_ptr<Encoding>> GpuEncodingFactory::createBatch(const std
   std::vector<std::unique_ptr<Encoding>> out;
   for (auto c : chunks) out.push_back(create(c, sbf, options));
   return out;
+}
+
+std::unique_ptr<DeviceBatch> GpuEncodingFactory::decodeToDevice(const std::vector<std::string_view>& chunks, const Options& options) const {
+  return decodeChunksToDevice(ctx_, chunks, options);
 }
 
 // ------------------------------------------------------------ stripe decoder

@@ -133,10 +133,32 @@ class GpuEncodingFactory {
                                                      StringBufferFactory stringBufferFactory,
                                                      const Options& options) const;
 
+  // Device-resident form, for consumers that run on the GPU themselves (no
+  // counterpart in the reference, whose vectors live in host memory): the
+  // chunks are decoded into a device buffer the returned object owns, and
+  // nothing is copied back.  This is the shape in which the decoder delivers
+  // its throughput; the Encoding objects above pay two PCIe crossings and two
+  // host copies for the same bytes.
+  std::unique_ptr<class DeviceBatch> decodeToDevice(const std::vector<std::string_view>& chunks, const Options& options) const;
+
  private:
   Options options_;
   Fallback fallback_;
   std::shared_ptr<GpuContext> ctx_;
+};
+
+// Decoded chunks left in device memory (GpuEncodingFactory::decodeToDevice).
+// layout(i) says where chunk i's values / null bitmap / string bytes sit
+// relative to data(), in the formats of nbl_chunk_layout.
+class DeviceBatch {
+ public:
+  virtual ~DeviceBatch() = default;
+  virtual size_t chunkCount() const = 0;
+  virtual const nbl_chunk_layout& layout(size_t chunk) const = 0;
+  virtual const void* data() const = 0;   // device pointer, bytes() long
+  virtual uint64_t bytes() const = 0;
+  virtual int device() const = 0;
+  virtual void* stream() const = 0;       // hipStream_t the decode ran on (already synchronised)
 };
 
 // nimble::Decoder (velox/Decoder.h:27-56) with std::vector<std::shared_ptr<void>>

@@ -6,6 +6,8 @@
 #include <string>
 #include <vector>
 
+#include <hip/hip_runtime_api.h>
+
 #include "nimble_gpu.h"
 #include "tablet.h"
 
@@ -161,6 +163,32 @@ int nblh_stripe_skip(void* s, uint32_t stream, uint32_t count) {
 }
 int nblh_stripe_reset(void* s, uint32_t stream) {
   return guard([&] { static_cast<StripeHandle*>(s)->dec->decoder(stream).reset(); });
+}
+
+// ---- device-resident batch ----------------------------------------------------
+void* nblh_decode_to_device(void* factory, const char* const* chunks, const uint64_t* sizes, uint32_t n) {
+  DeviceBatch* b = nullptr;
+  guard([&] {
+    std::vector<std::string_view> views;
+    for (uint32_t i = 0; i < n; ++i) views.emplace_back(chunks[i], sizes[i]);
+    auto& f = *static_cast<FactoryHandle*>(factory)->f;
+    b = f.decodeToDevice(views, f.options()).release();
+  });
+  return b;
+}
+void nblh_device_batch_free(void* b) { delete static_cast<DeviceBatch*>(b); }
+uint64_t nblh_device_batch_data(void* b) { return reinterpret_cast<uint64_t>(static_cast<DeviceBatch*>(b)->data()); }
+uint64_t nblh_device_batch_bytes(void* b) { return static_cast<DeviceBatch*>(b)->bytes(); }
+int nblh_device_batch_layout(void* b, uint32_t chunk, nbl_chunk_layout* out) {
+  return guard([&] { *out = static_cast<DeviceBatch*>(b)->layout(chunk); });
+}
+// test helper: the whole device buffer copied to `host` (bytes() long)
+int nblh_device_batch_copy_out(void* b, void* host) {
+  return guard([&] {
+    auto* B = static_cast<DeviceBatch*>(b);
+    if (B->bytes() && hipMemcpy(host, B->data(), B->bytes(), hipMemcpyDeviceToHost) != hipSuccess)
+      throw NimbleError(NBL_ERR_HIP, "hipMemcpy(device batch)");
+  });
 }
 
 // ---- tablet (file front-end) ------------------------------------------------

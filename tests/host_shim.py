@@ -60,6 +60,15 @@ def lib():
         L.nblh_stripe_next.argtypes = [vp, u32, u32, vp, vp, C.POINTER(i32), vp, u32, C.POINTER(u32), C.POINTER(u32)]
         L.nblh_stripe_skip.argtypes = [vp, u32, u32]
         L.nblh_stripe_reset.argtypes = [vp, u32]
+        L.nblh_decode_to_device.restype = vp
+        L.nblh_decode_to_device.argtypes = [vp, C.POINTER(C.c_char_p), vp, u32]
+        L.nblh_device_batch_free.argtypes = [vp]
+        L.nblh_device_batch_data.restype = u64
+        L.nblh_device_batch_data.argtypes = [vp]
+        L.nblh_device_batch_bytes.restype = u64
+        L.nblh_device_batch_bytes.argtypes = [vp]
+        L.nblh_device_batch_layout.argtypes = [vp, u32, vp]
+        L.nblh_device_batch_copy_out.argtypes = [vp, vp]
         u64p = C.POINTER(u64)
         L.nblh_tablet_open.restype = vp
         L.nblh_tablet_open.argtypes = [vp, u64]
@@ -262,3 +271,34 @@ class Tablet:
         sd = StripeDecoder.__new__(StripeDecoder)
         sd._factory, sd._streams, sd._h, sd._keep = factory, [], h, self
         return sd, ids[: n.value].tolist()
+
+
+class DeviceBatch:
+    """GpuEncodingFactory::decodeToDevice: decoded chunks left in device memory."""
+
+    def __init__(self, factory: Factory, chunks):
+        from nimble_amd import capi
+
+        self._chunks = [bytes(c) for c in chunks]
+        arr = (C.c_char_p * len(self._chunks))(*self._chunks)
+        sizes = np.array([len(c) for c in self._chunks], dtype=np.uint64)
+        self._h = lib().nblh_decode_to_device(factory._h, arr, _p(sizes), len(self._chunks))
+        if not self._h:
+            _chk(-1)
+        self.device_ptr = lib().nblh_device_batch_data(self._h)
+        self.bytes = lib().nblh_device_batch_bytes(self._h)
+        self.layouts = []
+        for i in range(len(self._chunks)):
+            lay = capi.NblChunkLayout()
+            _chk(lib().nblh_device_batch_layout(self._h, i, C.byref(lay)))
+            self.layouts.append(lay)
+
+    def to_host(self) -> np.ndarray:
+        out = np.zeros(max(int(self.bytes), 1), dtype=np.uint8)
+        _chk(lib().nblh_device_batch_copy_out(self._h, _p(out)))
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().nblh_device_batch_free(self._h)
+            self._h = None

@@ -223,3 +223,26 @@ def test_compressed_leaves_and_chunks_decode_like_their_uncompressed_twins(facto
         out = np.zeros(n, dtype=np.uint64)
         nn, _ = d.next(n, out)
         assert nn == n and np.array_equal(out, ints.view(np.uint64))
+
+
+def test_device_resident_batch(factory, oracle):
+    """decodeToDevice leaves the decoded chunks in device memory; copied back,
+    they are what the oracle decodes."""
+    import host_shim
+    from nimble_amd.decoder import slice_chunk
+    from util import assert_chunk_equal, oracle_chunk
+
+    rng = np.random.default_rng(31)
+    n = 30_000
+    mask = rng.random(n) < 0.7
+    encs = [
+        E.encode(E.FixedBitWidth(exact_bits=True), rng.integers(0, 1 << 11, n).astype(np.int32), W.INT32),
+        E.encode(E.RLE(), np.repeat(rng.integers(0, 9, n // 5), 5).astype(np.int64), W.INT64),
+        E.encode_nullable(E.Nullable(data=E.Trivial(), nulls=E.SparseBool()), rng.integers(0, 99, int(mask.sum())).astype(np.int64), mask, W.INT64),
+        E.encode(E.Dictionary(), random_strings(rng, 12).take(rng.integers(0, 12, n)), W.STRING),
+    ]
+    batch = host_shim.DeviceBatch(factory, encs)
+    assert batch.device_ptr != 0 and batch.bytes > 0
+    host = batch.to_host()
+    for enc, lay in zip(encs, batch.layouts):
+        assert_chunk_equal(slice_chunk(host, lay), oracle_chunk(oracle, enc), "device batch")
