@@ -153,3 +153,44 @@ def test_decode_without_gpu_fails_loudly():
     with pytest.raises(RuntimeError):
         BatchDecoder(p)
     p.close()
+
+
+def test_fused_and_per_operation_plans_agree_on_layout_and_bytes():
+    """The two launch shapes of a plan (one launch per cascade level / one per
+    operation) describe the same outputs; launches are ordered by level, the
+    fused plan has exactly one launch per level and both account the same
+    algorithmic bytes."""
+    from nimble_amd import workloads as WL
+
+    chunks = WL.mixed_table_stripe(stripe=1, rows=3000)
+    buf, offs = WL.pack_chunks(chunks)
+    fused, per_op = Plan(buf, offs), Plan(buf, offs, per_kernel=True)
+    assert fused.info.out_bytes == per_op.info.out_bytes and fused.info.work_bytes == per_op.info.work_bytes
+    for a, b in zip(fused.layouts, per_op.layouts):
+        assert bytes(a) == bytes(b)
+    lf, lp = fused.launches(), per_op.launches()
+    levels = [l[3] for l in lf]
+    assert levels == sorted(set(levels)) and len(lp) > len(lf)
+    assert {l[0] for l in lf} <= {"k_level<false>", "k_level<true>"} and lf[-1][0] == "k_level<true>"
+    assert sum(l[4] for l in lf) == sum(l[4] for l in lp) == fused.info.encoded_bytes + fused.info.decoded_bytes
+    assert sum(l[2] for l in lf) == sum(l[2] for l in lp)  # same tiles, grouped differently
+    assert [l[3] for l in lp] == sorted(l[3] for l in lp)
+    fused.close(); per_op.close()
+
+
+def test_leaf_only_chunks_fill_the_preparatory_levels():
+    """Chunks that are a single unpack / copy depend on nothing: their tiles are
+    dealt over the levels that the deeper cascades need, so no level is left
+    with only a handful of small tiles."""
+    rng = np.random.default_rng(3)
+    n = 400_000
+    leaf = [E.encode(E.FixedBitWidth(exact_bits=True), rng.integers(0, 1 << 9, n).astype(np.int64), W.INT64) for _ in range(6)]
+    deep = [E.encode(E.RLE(), np.repeat(rng.integers(0, 50, n // 20), 20).astype(np.int64), W.INT64)]
+    p = Plan.from_encodings(leaf + deep)
+    launches = p.launches()
+    assert len(launches) == 4  # reduce, scan, run ends, expand
+    tiles = [l[2] for l in launches]
+    assert min(tiles) > 100 and max(tiles) < 3 * min(tiles), tiles
+    only_deep = Plan.from_encodings(deep)
+    assert [l[2] for l in only_deep.launches()][1] == 1  # the scan level alone is one workgroup
+    p.close(); only_deep.close()
