@@ -42,7 +42,8 @@
  * these encodings and cannot be compiled offline (velox / folly / glog are
  * absent), so byte-level parity of the encodings is pinned only by the
  * reference's layout documentation, its tests' header facts and deterministic
- * inputs (see tests/test_oracle_pins.py): "parity unpinned" beyond those.
+ * inputs (tests/golden/make_golden.py, tests/test_oracle_golden.py,
+ * tests/test_oracle_semantics.py): "parity unpinned" beyond those.
  *
  * Plain C99, no dependencies.  All multi-byte fields little-endian, unaligned.
  */
