@@ -233,13 +233,28 @@ static void fbw_materialize(orc_enc* e, uint32_t n, void* buffer) {
   uint8_t* out = (uint8_t*)buffer;
   const uint64_t row = e->row;
   switch (e->es) {
-    case 8: { uint64_t* o = (uint64_t*)out; for (uint32_t i = 0; i < n; ++i) o[i] = fba_get(e, row + i) + e->baseline; break; }
-    case 4: { uint32_t* o = (uint32_t*)out; const uint32_t b = (uint32_t)e->baseline;
-              for (uint32_t i = 0; i < n; ++i) o[i] = (uint32_t)fba_get(e, row + i) + b; break; }
-    case 2: { uint16_t* o = (uint16_t*)out; const uint32_t b = (uint32_t)e->baseline;
-              for (uint32_t i = 0; i < n; ++i) o[i] = (uint16_t)((uint32_t)fba_get(e, row + i) + b); break; }
-    default: { const uint32_t b = (uint32_t)e->baseline;
-              for (uint32_t i = 0; i < n; ++i) out[i] = (uint8_t)((uint32_t)fba_get(e, row + i) + b); break; }
+    case 8: {
+      uint64_t* o = (uint64_t*)out;
+      for (uint32_t i = 0; i < n; ++i) o[i] = fba_get(e, row + i) + e->baseline;
+      break;
+    }
+    case 4: {
+      uint32_t* o = (uint32_t*)out;
+      const uint32_t b = (uint32_t)e->baseline;
+      for (uint32_t i = 0; i < n; ++i) o[i] = (uint32_t)fba_get(e, row + i) + b;
+      break;
+    }
+    case 2: {
+      uint16_t* o = (uint16_t*)out;
+      const uint32_t b = (uint32_t)e->baseline;
+      for (uint32_t i = 0; i < n; ++i) o[i] = (uint16_t)((uint32_t)fba_get(e, row + i) + b);
+      break;
+    }
+    default: {
+      const uint32_t b = (uint32_t)e->baseline;
+      for (uint32_t i = 0; i < n; ++i) out[i] = (uint8_t)((uint32_t)fba_get(e, row + i) + b);
+      break;
+    }
   }
   e->row += n;
 }
@@ -673,7 +688,7 @@ static orc_enc* orc_create_in(orc_ctx* c, const uint8_t* data, uint64_t size) {
 typedef struct orc_handle { orc_ctx ctx; orc_enc* root; } orc_handle;
 
 orc_handle* orc_create(const uint8_t* data, uint64_t size, int varint_rows, char* err, int errlen) {
-  orc_handle* h = (orc_handle*)calloc(1, sizeof(orc_handle));
+  orc_handle* volatile h = (orc_handle*)calloc(1, sizeof(orc_handle));
   h->ctx.varint_rows = varint_rows;
   if (setjmp(h->ctx.jb)) {
     if (err && errlen > 0) { snprintf(err, (size_t)errlen, "%s", h->ctx.err); }
@@ -770,12 +785,12 @@ static uint32_t nullable_materialize_nullable(orc_enc* e, uint32_t n, void* buff
 uint32_t orc_materialize_nullable(orc_handle* h, uint32_t n, void* buffer, void* nulls, int* nulls_requested,
                                   const void* scatter, uint32_t scatter_size, uint32_t offset) {
   int dummy = 0;
-  if (!nulls_requested) nulls_requested = &dummy;
+  int* volatile requested_out = nulls_requested ? nulls_requested : &dummy;
   ORC_GUARD(h, UINT32_MAX);
   orc_enc* e = h->root;
   if (e->etype == ET_NULLABLE)
-    return nullable_materialize_nullable(e, n, buffer, nulls, nulls_requested, scatter, scatter_size, offset);
-  return typed_materialize_nullable(e, n, buffer, nulls, nulls_requested, scatter, scatter_size, offset);
+    return nullable_materialize_nullable(e, n, buffer, nulls, requested_out, scatter, scatter_size, offset);
+  return typed_materialize_nullable(e, n, buffer, nulls, requested_out, scatter, scatter_size, offset);
 }
 
 /* Flatten orc_sv[n] into lengths + bytes (helper for ctypes callers). */
