@@ -1,7 +1,8 @@
 /*
  * nimble_amd.h -- C ABI of the MI355X-native decoder for Nimble's cascading
  * stream encodings (Trivial, FixedBitWidth, RLE, Dictionary, Nullable,
- * SparseBool, Constant, MainlyConstant, Varint).
+ * SparseBool, Constant, MainlyConstant, Varint, and the block encodings
+ * BlockBitPacking and FOR).
  *
  * The library replaces, for a *batch* of encoded chunks, what the reference
  * does one chunk at a time on the CPU:
@@ -40,7 +41,7 @@ enum {
    * NIMBLE_UNREACHABLE (dwio/nimble/common/Exceptions.h:111-155). */
   NBL_ERR_CORRUPT = 1,
   /* Well-formed Nimble that this library does not decode on the GPU
-   * (compressed payloads, experimental encodings): the caller delegates the
+   * (compressed payloads until inflated, the other experimental encodings): the caller delegates the
    * chunk to the reference's CPU EncodingFactory. */
   NBL_ERR_UNSUPPORTED = 2,
   NBL_ERR_HIP = 3,      /* a HIP runtime call failed */

@@ -56,6 +56,7 @@ enum KernelId : uint32_t {
   K_SELECT_BITS,       // Nullable<bool>: scatter a bitmap by a bitmap
   K_MATERIALIZE_FBW,   // root FixedBitWidth, window-per-vector fast path
   K_MATERIALIZE_RAW,   // root Trivial / byte-aligned FixedBitWidth: copy (+ baseline)
+  K_FRAME_UNPACK,      // BlockBitPacking blocks / FOR frames: per-segment baseline + width
   K_COUNT,
   // Launch ids of the fused launches: one launch runs every step of a cascade
   // level, each tile naming its own operation (TileRef::tile, high byte).
@@ -73,8 +74,12 @@ constexpr uint32_t make_op(uint32_t kernel, uint32_t es) { return kernel * 4u + 
 // Kernel families whose code depends on the element size; the others always use slot 0.
 constexpr bool kernel_has_es(uint32_t k) {
   return k == K_MATERIALIZE || k == K_MATERIALIZE_FBW || k == K_MATERIALIZE_RAW || k == K_RLE_EXPAND ||
-         k == K_SELECT_SCATTER || k == K_DICT_GATHER || k == K_VARINT_DECODE;
+         k == K_SELECT_SCATTER || k == K_DICT_GATHER || k == K_VARINT_DECODE || k == K_FRAME_UNPACK;
 }
+// Operations the fused level launch carries.  The block encodings are rare
+// (experimental in the reference) and their body would cost the fused kernel
+// registers it does not have to spare, so they keep a launch of their own.
+constexpr bool kernel_is_fusable(uint32_t k) { return k != K_FRAME_UNPACK; }
 constexpr uint32_t op_of(uint32_t kernel, uint32_t es) { return make_op(kernel, kernel_has_es(kernel) ? es : 1u); }
 
 enum NodeFlags : uint32_t {
@@ -82,6 +87,8 @@ enum NodeFlags : uint32_t {
   NF_WRITE_NULLS = 1u << 1,  // also emit the selection bitmap to out (Nullable root)
   NF_SPARSE_VALUE = 1u << 2, // SparseBool: listed positions are 1
   NF_FIRST_TRUE = 1u << 3,   // RLE<bool>: first run is true
+  NF_FRAME_BITS = 1u << 4,   // K_FRAME_UNPACK: FOR (u64 bit offsets, no raw marker) instead of
+                             // BlockBitPacking (u32 byte offsets, width 255 = raw block)
 };
 
 // Status bits OR-ed into work[status_off] by kernels that meet inconsistent data.
@@ -91,6 +98,7 @@ enum StatusBits : uint32_t {
   ST_SELECT_COUNT = 1u << 2,       // set bits != rows of the values child
   ST_VARINT_COUNT = 1u << 3,       // fewer varints than rowCount
   ST_STRING_BYTES = 1u << 4,       // string lengths exceed the blob
+  ST_FRAME_RANGE = 1u << 5,        // block / frame offset or bit width outside the packed payload
 };
 
 struct NodeDesc {
@@ -99,10 +107,13 @@ struct NodeDesc {
   ColRef c1;          // second input (run values / alphabet / selected values ...)
   ColRef sel;         // bitmap input (nulls / isCommon)
   uint64_t aux;       // fill value (Nullable: 0, MainlyConstant: common value);
-                      // K_COPY_BYTES: byte count; K_STRING_VIEWS: blob base offset
-  uint64_t aux_off;   // second array: run ends (work) / nulls bitmap (out) / copy src (arena)
+                      // K_COPY_BYTES: byte count; K_STRING_VIEWS: blob base offset;
+                      // K_FRAME_UNPACK: bytes of the packed payload
+  uint64_t aux_off;   // second array: run ends (work) / nulls bitmap (out) / copy src (arena) /
+                      // K_FRAME_UNPACK: packed payload (arena)
   uint64_t aux2;      // K_STRING_VIEWS: blob bytes; varint: payload byte count;
-                      // select kernels: rows per tile of the popcount partials
+                      // select kernels: rows per tile of the popcount partials;
+                      // K_FRAME_UNPACK: rows per segment | rows of the first segment << 32
   uint32_t rows;      // rows of this node
   uint32_t flags;     // NodeFlags
   uint32_t part_base; // first slot of this node in the tile-partials array

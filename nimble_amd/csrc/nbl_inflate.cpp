@@ -30,7 +30,7 @@ namespace {
 
 enum : uint8_t { CT_UNCOMPRESSED = 0, CT_ZSTD = 1, CT_LZ4 = 3 };  // common/Types.h:190-197
 enum : uint8_t { ET_TRIVIAL = 0, ET_RLE = 1, ET_DICTIONARY = 2, ET_FIXEDBITWIDTH = 3, ET_NULLABLE = 5, ET_SPARSEBOOL = 6,
-                 ET_VARINT = 7, ET_CONSTANT = 9, ET_MAINLYCONSTANT = 10 };
+                 ET_VARINT = 7, ET_CONSTANT = 9, ET_MAINLYCONSTANT = 10, ET_BLOCKBITPACKING = 15, ET_FOR = 18 };
 enum : uint8_t { DT_BOOL = 11, DT_STRING = 12 };
 
 struct Fail {
@@ -142,12 +142,46 @@ struct Walker {
       if (out) wr32(out + at, (uint32_t)n);
       pos += 4 + (uint64_t)csize;
     };
-    auto payload = [&](uint8_t ct) {  // the rest of the encoding is one (possibly compressed) payload
+    auto payload_of = [&](uint8_t ct, uint64_t bytes) {  // `bytes` at pos are one (possibly compressed) payload
       if (ct != CT_UNCOMPRESSED) any_compressed = true;
-      const uint64_t n = payload_size(ct, p + pos, size - pos);
-      if (out) payload_inflate(ct, p + pos, size - pos, out + o);
+      const uint64_t n = payload_size(ct, p + pos, bytes);
+      if (out) payload_inflate(ct, p + pos, bytes, out + o);
       o += n;
-      pos = size;
+      pos += bytes;
+      return n;
+    };
+    auto payload = [&](uint8_t ct) { payload_of(ct, size - pos); };  // the rest of the encoding
+    auto read_varint = [&]() {  // varint::readVarint32, common/Varint.h:104-125
+      uint32_t v = 0;
+      for (int k = 0; k < 5; ++k) {
+        INF_CHECK(pos < size, "varint beyond end of encoding");
+        const uint8_t b = p[pos++];
+        v |= (uint32_t)(b & 127) << (7 * k);
+        if (!(b & 128)) break;
+      }
+      return v;
+    };
+    auto write_varint = [&](uint32_t v) {
+      uint8_t buf[5];
+      int n = 0;
+      while (v >= 128) { buf[n++] = (uint8_t)(128 | (v & 127)); v >>= 7; }
+      buf[n++] = (uint8_t)v;
+      copy(buf, (uint64_t)n);
+    };
+    auto copy_varints = [&](int count) {
+      const uint64_t from = pos;
+      for (int k = 0; k < count; ++k) (void)read_varint();
+      copy(p + from, pos - from);
+    };
+    // child preceded by its varint size, which is rewritten for the child's new size
+    auto varint_child = [&]() {
+      const uint32_t csize = read_varint();
+      INF_CHECK(csize <= size - pos, "child encoding beyond end of its parent");
+      const uint64_t n = rewrite(p + pos, csize, nullptr, depth + 1);
+      INF_CHECK(n <= 0xFFFFFFFFull, "rewritten child exceeds 4 GiB");
+      write_varint((uint32_t)n);
+      child(pos, csize);
+      pos += csize;
     };
     copy(p, prefix);
     switch (enc) {
@@ -192,6 +226,32 @@ struct Walker {
         sized_child();
         copy(p + pos, size - pos);  // the common value
         break;
+      case ET_BLOCKBITPACKING: {  // BlockBitPackingEncoding.h:311-348
+        INF_CHECK(pos + 1 <= size, "BlockBitPacking header beyond end");
+        const uint8_t ct = p[pos++];
+        const uint8_t zero = CT_UNCOMPRESSED;
+        copy(&zero, 1);
+        copy_varints(2);  // block size, block count
+        varint_child(); varint_child(); varint_child();  // baselines, bit widths, block offsets
+        copy_varints(1);  // rows of the first block
+        payload(ct);
+        break;
+      }
+      case ET_FOR: {  // ForEncoding.h:174-196
+        INF_CHECK(pos + 1 <= size, "FOR header beyond end");
+        const uint8_t ct = p[pos++];
+        const uint8_t zero = CT_UNCOMPRESSED;
+        copy(&zero, 1);
+        copy_varints(3);  // frame size, frame count, rows of the first frame
+        varint_child(); varint_child(); varint_child();  // bit widths, references, bit offsets
+        const uint32_t packed = read_varint();
+        INF_CHECK(packed <= size - pos, "FOR packed data beyond end");
+        const uint64_t usize = payload_size(ct, p + pos, packed);
+        INF_CHECK(usize <= 0xFFFFFFFFull, "FOR packed data exceeds 4 GiB");
+        write_varint((uint32_t)usize);
+        payload_of(ct, packed);
+        break;
+      }
       case ET_VARINT:
       case ET_CONSTANT:
         copy(p + pos, size - pos);

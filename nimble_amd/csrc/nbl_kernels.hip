@@ -1486,6 +1486,82 @@ __device__ __forceinline__ void body_copy_bytes(const KArgs& a, const NodeDesc& 
   }
 }
 
+// ------------------------------------------------------------ K_FRAME_UNPACK
+// BlockBitPacking (encodings/BlockBitPackingEncoding.h:746-784) and FOR
+// (encodings/ForEncoding.h:398-529): the rows are cut into segments (blocks /
+// frames) of aux2 rows, the first one possibly shorter; segment s has its own
+// baseline c0[s], bit width c1[s] and start sel[s] in the packed payload (byte
+// offset for blocks, bit offset for frames).  Inside a segment the values are a
+// plain LSB-first bit stream.  The three per-segment arrays are element arrays
+// in work.  Every lane decodes 16 bytes of consecutive rows per round and keeps
+// the segment's parameters while the rows stay inside it.
+__device__ __forceinline__ uint64_t bits_get(const uint8_t* payload, uint64_t bit, uint32_t w) {
+  const uint8_t* p = payload + (bit >> 3);
+  const uint32_t sh = (uint32_t)bit & 7u;
+  uint64_t v = ldu64(p) >> sh;
+  if (w + sh > 64) v |= (uint64_t)p[8] << (64 - sh);
+  return v & wmask(w);
+}
+template <int ES>
+__device__ __forceinline__ void body_frame_unpack(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t*) {
+  using T = typename ElemT<ES>::type;
+  constexpr uint32_t V = 16 / ES;
+  constexpr uint32_t TE = kTileBytes / ES;
+  const uint32_t rows = nd.rows;
+  const uint32_t start = tile * TE;
+  T* dst = reinterpret_cast<T*>(self_ptr(nd, a));
+  const T* bases = reinterpret_cast<const T*>(a.work + nd.c0.off);
+  const uint8_t* widths = a.work + nd.c1.off;
+  const uint8_t* offs = a.work + nd.sel.off;
+  const bool frames = (nd.flags & NF_FRAME_BITS) != 0;
+  const uint32_t seg_size = (uint32_t)nd.aux2, seg_first = (uint32_t)(nd.aux2 >> 32);
+  const uint8_t* payload = a.arena + nd.aux_off;
+  const uint64_t payload_bits = nd.aux * 8;
+  uint32_t bad = 0;
+#pragma unroll 1
+  for (uint32_t it = 0; it < 4; ++it) {
+    const uint32_t q0 = start + (it * kBlock + threadIdx.x) * V;
+    if (q0 >= rows) break;
+    Vec16<ES> x;
+    x.q = make_u32x4(0, 0, 0, 0);
+    uint32_t cur = ~0u, w = 0, seg_row0 = 0;
+    T base = 0;
+    uint64_t bit0 = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < V; ++j) {
+      const uint32_t row = q0 + j;
+      T val = 0;
+      if (row < rows) {
+        const uint32_t s = row < seg_first ? 0u : 1u + (row - seg_first) / seg_size;
+        if (s != cur) {
+          cur = s;
+          w = widths[s];
+          base = bases[s];
+          seg_row0 = s ? seg_first + (s - 1u) * seg_size : 0u;
+          bit0 = frames ? reinterpret_cast<const uint64_t*>(offs)[s] : (uint64_t)reinterpret_cast<const uint32_t*>(offs)[s] * 8u;
+        }
+        const uint32_t r = row - seg_row0;
+        if (!frames && w == 255u) {  // block stored as raw values
+          const uint64_t byte = (bit0 >> 3) + (uint64_t)r * ES;
+          if ((byte + ES) * 8u <= payload_bits) val = ld_elem<ES>(payload + byte);
+          else bad = 1;
+        } else if (w == 0) {
+          val = base;
+        } else if (w > 64u || (!frames && w >= 8u * ES)) {
+          bad = 1;
+        } else {
+          const uint64_t bit = bit0 + (uint64_t)r * w;
+          if (bit <= payload_bits && w <= payload_bits - bit) val = (T)(bits_get(payload, bit, w) + base);
+          else bad = 1;
+        }
+      }
+      vec_set<ES>(x, j, val);
+    }
+    store_vec<ES>(dst, q0, rows, x);
+  }
+  if (bad) atomicOr(a.status, ST_FRAME_RANGE);
+}
+
 // ================================================================ dispatch
 // run_op<OP>: the body of operation OP = make_op(kernel, element size).
 template <uint32_t OP>
@@ -1510,6 +1586,7 @@ __device__ __forceinline__ void run_op(const KArgs& a, const NodeDesc& nd, uint3
   else if constexpr (K == K_VARINT_DECODE) body_varint_decode<(ES == 4 ? 4 : 8)>(a, nd, tile, smem);
   else if constexpr (K == K_STRING_VIEWS) body_string_views(a, nd, tile, smem);
   else if constexpr (K == K_COPY_BYTES) body_copy_bytes(a, nd, tile, smem);
+  else if constexpr (K == K_FRAME_UNPACK) body_frame_unpack<ES>(a, nd, tile, smem);
 }
 
 // One kernel per operation (used when the plan is not fused: profiling, tuning).
@@ -1541,6 +1618,7 @@ NBL_KERNEL_ES(k_dict_gather, K_DICT_GATHER)
 NBL_KERNEL_ES(k_varint_decode, K_VARINT_DECODE)
 NBL_KERNEL(k_string_views, K_STRING_VIEWS)
 NBL_KERNEL(k_copy_bytes, K_COPY_BYTES)
+NBL_KERNEL_ES(k_frame_unpack, K_FRAME_UNPACK)
 #undef NBL_KERNEL_ES
 #undef NBL_KERNEL
 
@@ -1577,7 +1655,7 @@ __global__ __launch_bounds__(256, 8) void k_level(KArgs a) {
     NBL_OP(K_VARINT_DECODE, 8)
     NBL_OP(K_STRING_VIEWS, 1)
     NBL_OP(K_COPY_BYTES, 1)
-    default: break;
+    default: break;  // K_FRAME_UNPACK is always launched on its own (kernel_is_fusable)
   }
 #undef NBL_OP_ALL_ES
 #undef NBL_OP
@@ -1628,6 +1706,7 @@ extern "C" int nbl_launch_kernel(uint32_t kernel, uint32_t es, const nbl::KArgs*
       break;
     case K_STRING_VIEWS: hipLaunchKernelGGL(k_string_views, grid, block, 0, s, a); break;
     case K_COPY_BYTES: hipLaunchKernelGGL(k_copy_bytes, grid, block, 0, s, a); break;
+    case K_FRAME_UNPACK: NBL_BY_ES(k_frame_unpack); break;
     default: return -1;
   }
 #undef NBL_BY_ES

@@ -51,7 +51,7 @@ struct PlanError {
 enum : uint8_t {
   ET_TRIVIAL = 0, ET_RLE = 1, ET_DICTIONARY = 2, ET_FIXEDBITWIDTH = 3, ET_SENTINEL = 4,
   ET_NULLABLE = 5, ET_SPARSEBOOL = 6, ET_VARINT = 7, ET_DELTA = 8, ET_CONSTANT = 9,
-  ET_MAINLYCONSTANT = 10, ET_MAX_KNOWN = 22
+  ET_MAINLYCONSTANT = 10, ET_BLOCKBITPACKING = 15, ET_FOR = 18, ET_MAX_KNOWN = 22
 };
 enum : uint8_t {
   DT_UNDEFINED = 0, DT_INT8 = 1, DT_UINT8 = 2, DT_INT16 = 3, DT_UINT16 = 4, DT_INT32 = 5,
@@ -71,7 +71,7 @@ struct PNode {
   bool is_bool = false, is_string = false;
   uint32_t rows = 0;
   uint64_t off = 0, size = 0;  // span of the encoding in the arena
-  int child[2] = {-1, -1};
+  int child[3] = {-1, -1, -1};
   int chunk = -1;
   int depth = 0;
   // leaf parameters
@@ -80,6 +80,7 @@ struct PNode {
   uint64_t value = 0;        // baseline, constant, common value (strings: view)
   uint8_t width = 0;
   uint8_t flag = 0;          // sparse value / first bool
+  uint32_t seg_size = 0, seg_first = 0, seg_count = 0;  // BlockBitPacking blocks / FOR frames
   // string constants (Constant<string>, MainlyConstant<string> common value)
   uint64_t str_off = 0;      // arena offset of the string bytes
   uint32_t str_len = 0;
@@ -114,7 +115,7 @@ const char* kKernelNames[K_COUNT] = {
     "k_materialize", "k_bits_to_bytes", "k_reduce_sum", "k_reduce_popc", "k_reduce_varint",
     "k_scan_tiles", "k_rle_ends", "k_rle_expand", "k_rle_expand_bool", "k_sparse_bits",
     "k_select_scatter", "k_dict_gather", "k_varint_decode", "k_string_views", "k_copy_bytes",
-    "k_select_bits", "k_materialize_fbw", "k_materialize_raw"};
+    "k_select_bits", "k_materialize_fbw", "k_materialize_raw", "k_frame_unpack"};
 
 }  // namespace
 
@@ -399,6 +400,59 @@ int nbl_plan::parse(uint64_t off, uint64_t size, int chunk, int depth) {
       NBL_CHECK(pos == end, "Unexpected mainly constant encoding end");
       break;
     }
+    case ET_BLOCKBITPACKING:  // BlockBitPackingEncoding.h:311-348,660-696
+    case ET_FOR: {            // ForEncoding.h:174-196,316-383
+      const bool frames = n.enc == ET_FOR;
+      const char* name = frames ? "FOR" : "BlockBitPacking";
+      if (frames) NBL_CHECK(n.dtype >= DT_INT8 && n.dtype <= DT_UINT64, "FOR needs an integer data type");
+      else NBL_CHECK(!n.is_bool && !n.is_string, "BlockBitPacking needs a numeric data type");
+      auto varint = [&]() {  // varint::readVarint32, common/Varint.h:104-125
+        uint32_t v = 0;
+        for (int k = 0; k < 5; ++k) {
+          NBL_CHECK(pos < end, "%s header beyond end", name);
+          const uint8_t b = u8(pos++);
+          v |= (uint32_t)(b & 127) << (7 * k);
+          if (!(b & 128)) break;
+        }
+        return v;
+      };
+      auto meta = [&](int slot, uint32_t es, const char* what) {  // varint size + nested encoding of one value per segment
+        const uint32_t csize = varint();
+        const int c = child(slot, pos, csize);
+        NBL_CHECK(!nodes[c].is_bool && !nodes[c].is_string && nodes[c].es == es, "%s %s have the wrong element size", name, what);
+        NBL_CHECK(nodes[c].rows >= N().seg_count, "%s has fewer %s than blocks", name, what);
+        pos += csize;
+      };
+      NBL_CHECK(pos + 1 <= end, "%s header beyond end", name);
+      if (u8(pos) != 0) fail(NBL_ERR_UNSUPPORTED, "compressed %s payload (CompressionType %d)", name, (int)u8(pos));
+      pos += 1;
+      N().seg_size = varint();
+      N().seg_count = varint();
+      if (frames) {
+        N().seg_first = varint();
+      } else {  // both fields are read into uint16_t; block size is capped by kBlockBitPackingBlockSize
+        N().seg_size &= 0xFFFFu;
+        N().seg_count &= 0xFFFFu;
+        NBL_CHECK(N().seg_size <= 1024, "BlockBitPacking block size exceeds 1024");
+      }
+      NBL_CHECK(N().seg_size > 0 && N().seg_count > 0 && n.rows > 0, "%s needs rows, a block size and blocks", name);
+      if (frames) { meta(1, 1, "bit widths"); meta(0, n.es, "references"); meta(2, 8, "bit offsets"); }
+      else { meta(0, n.es, "baselines"); meta(1, 1, "bit widths"); meta(2, 4, "block offsets"); N().seg_first = varint(); }
+      const uint32_t first = N().seg_first, size = N().seg_size;
+      NBL_CHECK(first > 0 && first <= size && first <= n.rows, "%s first block rows out of range", name);
+      const uint64_t expect = n.rows <= first ? 1 : 1 + ((uint64_t)(n.rows - first) + size - 1) / size;
+      NBL_CHECK(N().seg_count == expect, "%s frame count mismatch.", name);
+      if (frames) {
+        const uint32_t packed = varint();
+        NBL_CHECK(packed <= end - pos, "FOR packed data beyond end");
+        N().payload_off = pos;
+        N().payload_bytes = packed;
+      } else {
+        N().payload_off = pos;
+        N().payload_bytes = end - pos;
+      }
+      break;
+    }
     default:
       // Delta, Prefix, ALP, PFOR, ... : valid Nimble, decoded by the CPU factory.
       fail(NBL_ERR_UNSUPPORTED, "EncodingType %d is not decoded on the GPU", (int)n.enc);
@@ -461,11 +515,11 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
   PNode& nn = nodes[idx];  // `nodes` no longer grows once parsing is done
   const uint32_t rows = nn.rows;
   // children first
-  for (int s = 0; s < 2; ++s)
+  for (int s = 0; s < 3; ++s)
     if (nn.child[s] >= 0) place(nn.child[s], false, nullptr);
   auto C = [&](int s) -> PNode& { return nodes[nn.child[s]]; };
   int lvl = 0;
-  for (int s = 0; s < 2; ++s)
+  for (int s = 0; s < 3; ++s)
     if (nn.child[s] >= 0) lvl = std::max(lvl, C(s).ready);
 
   auto mat_ref = [&](uint32_t es) {  // destination of a materialised numeric / view column
@@ -642,6 +696,36 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       nn.ref = d.self; nn.ready = lvl + 3;
       break;
     }
+    case ET_BLOCKBITPACKING:
+    case ET_FOR: {
+      // the per-segment arrays (baselines, widths, offsets) are small: whatever
+      // their encoding, the unpack reads them as element arrays in work
+      auto as_array = [&](int slot, uint32_t ces) {
+        PNode& ch = C(slot);
+        if (ch.ref.kind == COL_MAT_WORK) return ch.ref;
+        NodeDesc m{};
+        m.self.kind = COL_MAT_WORK; m.self.off = alloc_work((uint64_t)nn.seg_count * ces);
+        m.self.rows = nn.seg_count; m.self.es = (uint8_t)ces;
+        m.c0 = ch.ref; m.c0.rows = nn.seg_count; m.rows = nn.seg_count;
+        const uint32_t mn = add_dnode(m);
+        add_step(ch.ready, leaf_kernel(ch.ref, ces), ces, mn, div_up32(nn.seg_count, kTileBytes / ces));
+        lvl = std::max(lvl, ch.ready + 1);
+        return m.self;
+      };
+      NodeDesc d{};
+      d.c0 = as_array(0, es);
+      d.c1 = as_array(1, 1);
+      d.sel = as_array(2, nn.enc == ET_FOR ? 8 : 4);
+      d.self = mat_ref(es);
+      d.rows = rows;
+      d.aux = nn.payload_bytes; d.aux_off = nn.payload_off;
+      d.aux2 = (uint64_t)nn.seg_size | ((uint64_t)nn.seg_first << 32);
+      if (nn.enc == ET_FOR) d.flags |= NF_FRAME_BITS;
+      const uint32_t dn = add_dnode(d);
+      add_step(lvl, K_FRAME_UNPACK, es, dn, div_up32(rows, tile_rows));
+      nn.ref = d.self; nn.ready = lvl + 1;
+      break;
+    }
     default:
       fail(NBL_ERR_UNSUPPORTED, "EncodingType %d is not decoded on the GPU", (int)nn.enc);
   }
@@ -792,8 +876,12 @@ void nbl_plan::finish() {
     if (st.chunk >= 0) st.alg = chunk_alg[(size_t)st.chunk];
   if (fused && last_level > 0) spread_free_steps(last_level);
   {  // stable counting sort by (level, filler, kernel, element size): wide tables have ~10 steps per column
-    auto key = [](const Step& st) { return (((size_t)st.level * 2 + (st.filler ? 1 : 0)) * K_COUNT + st.kernel) * 4 + es_slot(st.es); };
-    std::vector<uint32_t> first((size_t)(last_level + 1) * 2 * K_COUNT * 4 + 1, 0);
+    // within a level: the level's own fusable steps, the fillers, then the steps that launch on their own
+    auto key = [](const Step& st) {
+      const size_t cls = !kernel_is_fusable(st.kernel) ? 2 : st.filler ? 1 : 0;
+      return (((size_t)st.level * 3 + cls) * K_COUNT + st.kernel) * 4 + es_slot(st.es);
+    };
+    std::vector<uint32_t> first((size_t)(last_level + 1) * 3 * K_COUNT * 4 + 1, 0);
     for (const Step& st : steps) ++first[key(st) + 1];
     for (size_t i = 1; i < first.size(); ++i) first[i] += first[i - 1];
     std::vector<Step> sorted(steps.size());
@@ -808,15 +896,16 @@ void nbl_plan::finish() {
   for (size_t i = 0; i < steps.size();) {
     size_t j = i;
     Launch L{steps[i].kernel, steps[i].es, (uint32_t)tiles.size(), 0, steps[i].level, 0, std::string()};
+    const bool fuse = fused && kernel_is_fusable(steps[i].kernel);
     while (j < steps.size() && steps[j].level == steps[i].level &&
-           (fused || (steps[j].kernel == steps[i].kernel && steps[j].es == steps[i].es))) {
+           (fuse ? kernel_is_fusable(steps[j].kernel) : (steps[j].kernel == steps[i].kernel && steps[j].es == steps[i].es))) {
       const uint32_t op = op_of(steps[j].kernel, steps[j].es) << kOpShift;
       for (uint32_t t = 0; t < steps[j].n_tiles; ++t) tiles.push_back(TileRef{steps[j].dnode, op | (steps[j].tile_begin + t)});
       L.alg_bytes += steps[j].alg;
       ++j;
     }
     L.n_tiles = (uint32_t)tiles.size() - L.tile_begin;
-    if (fused) {
+    if (fuse) {
       L.kernel = L.level == last_level ? K_LEVEL_LAST : K_LEVEL;
       L.es = 0;
       L.name = L.kernel == K_LEVEL_LAST ? "k_level<true>" : "k_level<false>";
@@ -1110,6 +1199,7 @@ nbl_status nbl_decode_status(const nbl_plan* p, const void* d_work, void* stream
   if (st & ST_SELECT_COUNT) m += " selected-row count differs from the values child;";
   if (st & ST_VARINT_COUNT) m += " fewer varints than rows;";
   if (st & ST_STRING_BYTES) m += " string lengths exceed the blob;";
+  if (st & ST_FRAME_RANGE) m += " block offset or bit width outside the packed payload;";
   g_last_error = m;
   return NBL_ERR_DEVICE_DATA;
 }

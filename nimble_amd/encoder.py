@@ -1,5 +1,6 @@
 """Test-vector / synthetic-table generator: a numpy writer for the nine
-production stream encodings of Nimble (uncompressed payloads only).
+production stream encodings of Nimble plus the two block encodings nearest to
+FixedBitWidth (BlockBitPacking, FOR).
 
 This is the *input fabricator* for tests and benchmarks -- the reference's own
 writer cannot be built offline.  Byte layouts follow the reference encoders:
@@ -15,6 +16,8 @@ writer cannot be built offline.  Byte layouts follow the reference encoders:
 * Constant .......... dwio/nimble/encodings/ConstantEncoding.h:163-200
 * MainlyConstant .... dwio/nimble/encodings/MainlyConstantEncoding.h:558-570,863-915
 * Varint ............ dwio/nimble/encodings/VarintEncoding.h:164-211
+* BlockBitPacking ... dwio/nimble/encodings/BlockBitPackingEncoding.h:559-594,1100-1227
+* FOR ............... dwio/nimble/encodings/ForEncoding.h:224-240,590-758
 * chunk framing ..... dwio/nimble/common/ChunkHeader.h:43-47
 
 Unlike the reference writer there is no selection policy: the caller names the
@@ -33,7 +36,7 @@ from . import wire as W
 
 __all__ = [
     "StringColumn", "Trivial", "FixedBitWidth", "Varint", "Constant", "RLE",
-    "Dictionary", "Nullable", "SparseBool", "MainlyConstant", "encode",
+    "Dictionary", "Nullable", "SparseBool", "MainlyConstant", "BlockBitPacking", "FOR", "encode",
     "encode_nullable", "encode_dictionary_from_indices", "nullable_wrap", "mainly_constant_from_parts",
     "chunk", "stream", "bitpack", "varint_bytes",
     "bits_required",
@@ -149,6 +152,33 @@ class MainlyConstant:
     other: object = field(default_factory=Trivial)
 
 
+@dataclass
+class BlockBitPacking:
+    """Blocks of `block_size` rows, each with its own baseline and exact bit
+    width; blocks that packing would not shrink are stored raw."""
+
+    baselines: object = field(default_factory=Trivial)
+    bit_widths: object = field(default_factory=Trivial)
+    offsets: object = field(default_factory=Trivial)
+    block_size: int = W.BBP_MAX_BLOCK_SIZE
+    first_block_rows: Optional[int] = None  # a sliced stream starts with a partial block
+    compression: Optional[str] = None  # "zstd" | "lz4": compress the packed blocks
+
+
+@dataclass
+class FOR:
+    """Frames of `frame_size` rows: per-frame minimum + residuals packed at a
+    per-frame width, frames laid back to back at BIT granularity."""
+
+    bit_widths: object = field(default_factory=Trivial)
+    references: object = field(default_factory=Trivial)
+    bit_offsets: object = field(default_factory=Trivial)
+    frame_size: int = 128
+    first_frame_rows: Optional[int] = None  # a sliced stream starts with a partial frame
+    exact_bits: bool = False  # widths 0..64 as needed instead of the writer's {1,2,4,8,16,32,64}
+    compression: Optional[str] = None
+
+
 # --------------------------------------------------------------------------
 # primitives
 # --------------------------------------------------------------------------
@@ -197,6 +227,37 @@ def bitpack(values: np.ndarray, width: int) -> bytes:
             words[:, wi + 1] |= col >> np.uint64(64 - sh)
     raw = words.reshape(-1).view(np.uint8)[:nbytes]
     return raw.tobytes() + bytes(W.FBA_SLOP)
+
+
+def _varint_string(data: bytes) -> bytes:
+    """varint length + bytes (encoding::writeVarintString)."""
+    return _write_varint(len(data)) + data
+
+
+def _segments(n: int, size: int, first: Optional[int]):
+    """Row ranges of the blocks / frames of an n-row stream: a first segment of
+    `first` rows (default `size`), then full segments, then the remainder."""
+    first = min(size if first is None else int(first), n)
+    assert 0 < first <= size
+    bounds = [0, first]
+    while bounds[-1] < n:
+        bounds.append(min(bounds[-1] + size, n))
+    return list(zip(bounds[:-1], bounds[1:]))
+
+
+def bitpack_variable(values: np.ndarray, widths: np.ndarray) -> tuple:
+    """LSB-first pack of value i into widths[i] bits, back to back at bit
+    granularity.  Returns (bytes of ceil(total/8), start bit of every value)."""
+    v = np.ascontiguousarray(values).astype(np.uint64, copy=False)
+    w = np.ascontiguousarray(widths).astype(np.int64, copy=False)
+    start = np.zeros(v.size + 1, dtype=np.int64)
+    np.cumsum(w, out=start[1:])
+    total = int(start[-1])
+    bits = np.zeros(total, dtype=np.uint8)
+    for k in range(int(w.max()) if w.size else 0):
+        m = w > k
+        bits[start[:-1][m] + k] = ((v[m] >> np.uint64(k)) & np.uint64(1)).astype(np.uint8)
+    return np.packbits(bits, bitorder="little").tobytes(), start[:-1]
 
 
 def varint_bytes(values: np.ndarray) -> bytes:
@@ -377,6 +438,66 @@ def encode(spec, values: Values, dtype: int, varint_rows: bool = False) -> bytes
             common = values[first_idx[best]:first_idx[best] + 1].tobytes()
         return (prefix(W.MAINLY_CONSTANT, dtype, n, vr) + struct.pack("<I", len(ic)) + ic +
                 struct.pack("<I", len(ov)) + ov + common)
+
+    if isinstance(spec, BlockBitPacking):
+        assert W.is_numeric(dtype) and n > 0, "BlockBitPacking cannot encode empty streams."
+        es = W.elem_bytes(dtype)
+        pt = W.physical_dtype(dtype)
+        segs = _segments(n, spec.block_size, spec.first_block_rows)
+        assert 0 < spec.block_size <= W.BBP_MAX_BLOCK_SIZE and len(segs) <= W.BBP_MAX_BLOCKS
+        baselines = np.zeros(len(segs), dtype=pt)
+        widths = np.zeros(len(segs), dtype=np.uint8)
+        offsets = np.zeros(len(segs), dtype=np.uint32)
+        parts, running = [], 0
+        for b, (s0, s1) in enumerate(segs):  # makeBlockInfo, BlockBitPackingEncoding.h:559-594
+            block = values[s0:s1]
+            lo, hi = int(block.min()), int(block.max())
+            bits = 0 if hi == lo else (hi - lo).bit_length()
+            raw_size = (s1 - s0) * es
+            packed_size = ((s1 - s0) * bits + 7) // 8 + W.FBA_SLOP
+            offsets[b] = running
+            if bits == 8 * es or packed_size >= raw_size:
+                widths[b] = W.BBP_RAW_BLOCK
+                parts.append(block.tobytes())
+            else:
+                baselines[b], widths[b] = lo, bits
+                parts.append(bitpack(block - block.dtype.type(lo), bits) if bits else bytes(W.FBA_SLOP))
+            running += len(parts[-1])
+        ct, body = compress_payload(b"".join(parts), spec.compression)
+        unsigned = {1: W.UINT8, 2: W.UINT16, 4: W.UINT32, 8: W.UINT64}[es]
+        return (prefix(W.BLOCK_BIT_PACKING, dtype, n, vr) + bytes([ct]) + _write_varint(spec.block_size) +
+                _write_varint(len(segs)) + _varint_string(encode(spec.baselines, baselines, unsigned, vr)) +
+                _varint_string(encode(spec.bit_widths, widths, W.UINT8, vr)) +
+                _varint_string(encode(spec.offsets, offsets, W.UINT32, vr)) + _write_varint(segs[0][1]) + body)
+
+    if isinstance(spec, FOR):
+        assert dtype in W.INTEGER_TYPES and n > 0, "Cannot encode empty data with ForEncoding."
+        es = W.elem_bytes(dtype)
+        pt = W.physical_dtype(dtype)
+        segs = _segments(n, spec.frame_size, spec.first_frame_rows)
+        refs = np.zeros(len(segs), dtype=pt)
+        widths = np.zeros(len(segs), dtype=np.uint8)
+        row_width = np.zeros(n, dtype=np.int64)
+        residual = np.zeros(n, dtype=np.uint64)
+        for f, (s0, s1) in enumerate(segs):  # ForEncoding.h:653-692
+            frame = values[s0:s1]
+            lo, hi = int(frame.min()), int(frame.max())
+            need = (hi - lo).bit_length()
+            if spec.exact_bits:
+                bw = need
+            else:  # minBitWidth, :227-240
+                bw = next(w for w in (1, 2, 4, 8, 16, 32, 64) if w >= max(need, 1))
+            refs[f], widths[f] = lo, bw
+            row_width[s0:s1] = bw
+            residual[s0:s1] = (frame - frame.dtype.type(lo)).astype(np.uint64)
+        packed, start = bitpack_variable(residual, row_width)
+        bit_offsets = np.array([int(start[s0]) if s0 < n else 0 for s0, _ in segs], dtype=np.uint64)
+        ct, body = compress_payload(packed, spec.compression)
+        unsigned = {1: W.UINT8, 2: W.UINT16, 4: W.UINT32, 8: W.UINT64}[es]
+        return (prefix(W.FOR, dtype, n, vr) + bytes([ct]) + _write_varint(spec.frame_size) + _write_varint(len(segs)) +
+                _write_varint(segs[0][1]) + _varint_string(encode(spec.bit_widths, widths, W.UINT8, vr)) +
+                _varint_string(encode(spec.references, refs, unsigned, vr)) +
+                _varint_string(encode(spec.bit_offsets, bit_offsets, W.UINT64, vr)) + _write_varint(len(body)) + body)
 
     if isinstance(spec, Nullable):
         raise TypeError("use encode_nullable() for Nullable cascades")

@@ -309,6 +309,12 @@ class GpuEncoding final : public Encoding {
     for (uint32_t i = 0; i < n; ++i) values_[r + i] ? bitSet(buffer, (uint64_t)begin + i) : bitClear(buffer, (uint64_t)begin + i);
   }
 
+  // cursor-free read of rows [offset, offset + length), for EncodingView
+  void readRows(uint32_t offset, uint32_t length, void* buffer) const {
+    if (offset > lay_.rows || length > lay_.rows - offset) throw NimbleError(NBL_ERR_ARGUMENT, "read range beyond the row count");
+    copyRows(offset, length, buffer, 0);
+  }
+
  private:
   uint32_t advance(uint32_t n) {
     if ((uint64_t)row_ + n > lay_.rows) throw NimbleError(NBL_ERR_ARGUMENT, "read past the end of the encoding");
@@ -348,6 +354,26 @@ class GpuEncoding final : public Encoding {
   const uint8_t* dictAlphabet_ = nullptr;
   const uint32_t* dictIndices_ = nullptr;
   std::vector<std::string_view> dictStrings_;
+};
+
+// EncodingView over a decoded chunk; owns the memory its string views point into.
+class GpuEncodingView final : public EncodingView {
+ public:
+  GpuEncodingView(std::unique_ptr<Encoding> enc, std::shared_ptr<std::vector<std::unique_ptr<char[]>>> strings)
+      : enc_(std::move(enc)), strings_(std::move(strings)) {}
+  void readAt(uint32_t index, void* output) const override {
+    if (index >= enc_->rowCount()) throw NimbleError(NBL_ERR_ARGUMENT, "row index beyond the row count");
+    rows().readRows(index, 1, output);
+  }
+  void read(uint32_t offset, uint32_t length, void* output) const override { rows().readRows(offset, length, output); }
+  uint32_t rowCount() const override { return enc_->rowCount(); }
+  EncodingType encodingType() const override { return enc_->encodingType(); }
+  DataType dataType() const override { return enc_->dataType(); }
+
+ private:
+  const GpuEncoding& rows() const { return static_cast<const GpuEncoding&>(*enc_); }
+  std::unique_ptr<Encoding> enc_;
+  std::shared_ptr<std::vector<std::unique_ptr<char[]>>> strings_;
 };
 
 // fn(i) for i in [0, n) on a few threads when there is enough to move; an
@@ -521,6 +547,33 @@ std::unique_ptr<Encoding> GpuEncodingFactory::create(std::string_view data, Stri
     if (fallback_) return fallback_(data, sbf);
     throw;
   }
+}
+
+bool supportsEncodingView(EncodingType t) {
+  switch (t) {
+    case EncodingType::Constant: case EncodingType::Trivial: case EncodingType::MainlyConstant:
+    case EncodingType::FixedBitWidth: case EncodingType::Dictionary: case EncodingType::SparseBool:
+    case EncodingType::RLE: case EncodingType::FOR: case EncodingType::BlockBitPacking:
+      return true;
+    default:
+      return false;
+  }
+}
+
+std::unique_ptr<EncodingView> GpuEncodingFactory::createEncodingView(std::string_view data, const Options& options) const {
+  if (data.empty()) throw NimbleError(NBL_ERR_CORRUPT, "encoding shorter than its prefix");
+  const auto type = static_cast<EncodingType>(static_cast<uint8_t>(data[0]));
+  if (!supportsEncodingView(type))
+    throw NimbleUnsupported(NBL_ERR_UNSUPPORTED, "EncodingType " + std::to_string((int)type) + " does not support EncodingView.");
+  auto strings = std::make_shared<std::vector<std::unique_ptr<char[]>>>();
+  auto sbf = [strings](uint32_t bytes) -> void* {
+    strings->push_back(std::make_unique<char[]>(bytes ? bytes : 1));
+    return strings->back().get();
+  };
+  Options o = options;
+  o.keepDictionary = false;
+  auto v = decodeChunks(*ctx_, {data}, sbf, o);  // no CPU fallback: a view is a GPU-decoded chunk or an error
+  return std::make_unique<GpuEncodingView>(std::move(v[0]), std::move(strings));
 }
 
 std::vector<std::unique_ptr<Encoding>> GpuEncodingFactory::createBatch(const std::vector<std::string_view>& chunks,

@@ -6,6 +6,8 @@
 //   nimble::EncodingFactory ..... dwio/nimble/encodings/common/EncodingFactory.h:32-55
 //   nimble::Decoder ............. dwio/nimble/velox/Decoder.h:27-56
 //   ChunkedStreamDecoder ........ dwio/nimble/velox/ChunkedStreamDecoder.h:25-74
+//   nimble::EncodingView ........ dwio/nimble/encodings/views/EncodingView.h:32-104,
+//                                 encodings/views/EncodingViewFactory.h:36-46
 //
 // Velox is not available to this build, so the two Velox types in those
 // signatures are replaced by the smallest equivalents: the MemoryPool argument
@@ -52,7 +54,7 @@ struct Bitmap {
 
 enum class EncodingType : uint8_t {
   Trivial = 0, RLE = 1, Dictionary = 2, FixedBitWidth = 3, Sentinel = 4, Nullable = 5, SparseBool = 6,
-  Varint = 7, Delta = 8, Constant = 9, MainlyConstant = 10
+  Varint = 7, Delta = 8, Constant = 9, MainlyConstant = 10, BlockBitPacking = 15, FOR = 18
 };
 enum class DataType : uint8_t {
   Undefined = 0, Int8 = 1, Uint8 = 2, Int16 = 3, Uint16 = 4, Int32 = 5, Uint32 = 6, Int64 = 7, Uint64 = 8,
@@ -103,6 +105,23 @@ class Encoding {
   }
 };
 
+// Same contract as nimble::EncodingView: cursor-free random access to the
+// physical values of one stream.  readAt / read write physicalType (bool: one
+// byte, string: std::string_view into memory the view owns); a range outside
+// [0, rowCount()] throws.
+class EncodingView {
+ public:
+  virtual ~EncodingView() = default;
+  virtual void readAt(uint32_t index, void* output) const = 0;
+  virtual void read(uint32_t offset, uint32_t length, void* output) const = 0;
+  virtual uint32_t rowCount() const = 0;
+  virtual EncodingType encodingType() const = 0;
+  virtual DataType dataType() const = 0;
+};
+// supportsEncodingView (EncodingViewFactory.cpp:161-182) restricted to the
+// encodings this library decodes.
+bool supportsEncodingView(EncodingType encodingType);
+
 class GpuContext;  // device, stream and reusable device buffers
 
 // Mirror of nimble::EncodingFactory with the decode running on the GPU.  A
@@ -132,6 +151,14 @@ class GpuEncodingFactory {
   std::vector<std::unique_ptr<Encoding>> createBatch(const std::vector<std::string_view>& chunks,
                                                      StringBufferFactory stringBufferFactory,
                                                      const Options& options) const;
+
+  // createEncodingView(data, pool, options) (EncodingViewFactory.h:42-46): the
+  // stream is decoded once on the GPU and the view serves reads from the
+  // decoded rows, so readAt is an array lookup whatever the encoding.  Throws
+  // NimbleUnsupported for encodings the reference has no view for (Nullable,
+  // Varint) as well as for those this library does not decode.
+  std::unique_ptr<EncodingView> createEncodingView(std::string_view data, const Options& options) const;
+  std::unique_ptr<EncodingView> createEncodingView(std::string_view data) const { return createEncodingView(data, options_); }
 
   // Device-resident form, for consumers that run on the GPU themselves (no
   // counterpart in the reference, whose vectors live in host memory): the

@@ -129,6 +129,24 @@ int nblh_dictionary_size(void* e, uint32_t* size) { return guard([&] { *size = E
 int nblh_dictionary_entries(void* e, const void** entries) { return guard([&] { *entries = E(e).dictionaryEntries(); }); }
 int nblh_materialize_indices(void* e, uint32_t n, uint32_t* buffer) { return guard([&] { E(e).materializeIndices(n, buffer); }); }
 
+// ---- encoding view ------------------------------------------------------------
+int nblh_supports_encoding_view(int encoding_type) { return supportsEncodingView(static_cast<EncodingType>(encoding_type)); }
+void* nblh_view_create(void* factory, const char* data, uint64_t size) {
+  EncodingView* v = nullptr;
+  guard([&] { v = static_cast<FactoryHandle*>(factory)->f->createEncodingView(std::string_view(data, size)).release(); });
+  return v;
+}
+void nblh_view_free(void* v) { delete static_cast<EncodingView*>(v); }
+uint32_t nblh_view_row_count(void* v) { return static_cast<EncodingView*>(v)->rowCount(); }
+int nblh_view_encoding_type(void* v) { return (int)static_cast<EncodingView*>(v)->encodingType(); }
+int nblh_view_data_type(void* v) { return (int)static_cast<EncodingView*>(v)->dataType(); }
+int nblh_view_read(void* v, uint32_t offset, uint32_t length, void* output) {
+  return guard([&] { static_cast<EncodingView*>(v)->read(offset, length, output); });
+}
+int nblh_view_read_at(void* v, uint32_t index, void* output) {
+  return guard([&] { static_cast<EncodingView*>(v)->readAt(index, output); });
+}
+
 // ---- stripe decoder --------------------------------------------------------
 void* nblh_stripe_create(void* factory, const char* const* streams, const uint64_t* sizes, uint32_t n) {
   StripeHandle* h = new StripeHandle();

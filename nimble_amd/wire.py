@@ -20,6 +20,8 @@ VARINT = 7
 DELTA = 8
 CONSTANT = 9
 MAINLY_CONSTANT = 10
+BLOCK_BIT_PACKING = 15  # experimental in the reference
+FOR = 18  # experimental in the reference
 
 ENCODING_NAMES = {
     TRIVIAL: "Trivial",
@@ -33,6 +35,8 @@ ENCODING_NAMES = {
     DELTA: "Delta",
     CONSTANT: "Constant",
     MAINLY_CONSTANT: "MainlyConstant",
+    BLOCK_BIT_PACKING: "BlockBitPacking",
+    FOR: "FOR",
 }
 
 # DataType (dwio/nimble/common/Types.h:169-183)
@@ -73,6 +77,11 @@ LZ4 = 3
 CHUNK_HEADER_SIZE = 5  # dwio/nimble/common/ChunkHeader.h:28
 FIXED_PREFIX_SIZE = 6  # dwio/nimble/encodings/common/EncodingPrefix.h:39
 FBA_SLOP = 7  # dwio/nimble/common/FixedBitArray.cpp:26-31
+BBP_RAW_BLOCK = 255  # BlockBitPackingEncoding.h:65: bit-width marker of a block stored as raw values
+BBP_MAX_BLOCK_SIZE = 1024  # dwio/nimble/common/Constants.h:51
+BBP_MAX_BLOCKS = 65535  # BlockBitPackingEncoding.h:69-70
+
+INTEGER_TYPES = (1, 2, 3, 4, 5, 6, 7, 8)
 
 
 def elem_bytes(dtype: int) -> int:

@@ -27,6 +27,9 @@
  *                             :842-860, encodings/MainlyConstantEncoding.cpp:21-43
  *   Varint .................. encodings/VarintEncoding.h:94-140,
  *                             common/Varint.h:83-143
+ *   BlockBitPacking ......... encodings/BlockBitPackingEncoding.h:311-348,660-874
+ *   FOR ..................... encodings/ForEncoding.h:174-196,316-383,398-546
+ *   EncodingView read ....... encodings/views/EncodingView.h:32-104
  *   scatter for non-nullable  encodings/common/Encoding.h:412-460
  *   chunk framing ........... common/ChunkHeader.h:36-40,
  *                             velox/ChunkedStream.cpp:36-72
@@ -36,7 +39,13 @@
  * 351b0a72f446c75e0bd0ad179063a7a02f8894fc: bits::fillBits / copyBits /
  * setBit / clearBit / isBitSet / findSetBit, Bitmap / BitmapBuilder,
  * simd::simdFill) is restated from its published, unambiguous semantics; the
- * reference pins those in common/tests/BitsTests.cpp:33-112.
+ * reference pins those in common/tests/BitsTests.cpp:33-112.  BlockBitPacking
+ * unpacks full groups with velox's copy of Lemire's fastunpack (same pin,
+ * velox/dwio/common/Lemire/BitPacking/bitpackinghelpers.h): the published
+ * layout of that scalar packer is the plain LSB-first bit stream, which is also
+ * what the reference's FixedBitArray tail and its 64-bit writer
+ * (bulkSetWithBaseline, BlockBitPackingEncoding.h:224-227) use for the same
+ * blocks, so one block is one FixedBitArray image here.
  *
  * Parity pin status: the reference holds no encoded-byte golden vectors for
  * these encodings and cannot be compiled offline (velox / folly / glog are
@@ -57,7 +66,7 @@
 enum {
   ET_TRIVIAL = 0, ET_RLE = 1, ET_DICTIONARY = 2, ET_FIXEDBITWIDTH = 3, ET_SENTINEL = 4,
   ET_NULLABLE = 5, ET_SPARSEBOOL = 6, ET_VARINT = 7, ET_DELTA = 8, ET_CONSTANT = 9,
-  ET_MAINLYCONSTANT = 10
+  ET_MAINLYCONSTANT = 10, ET_BLOCKBITPACKING = 15, ET_FOR = 18
 };
 enum {
   DT_UNDEFINED = 0, DT_INT8 = 1, DT_UINT8 = 2, DT_INT16 = 3, DT_UINT16 = 4, DT_INT32 = 5,
@@ -106,6 +115,10 @@ struct orc_enc {
   /* dictionary alphabet */
   uint8_t* alphabet; uint32_t alphabet_count;
   const char* blob; uint64_t blob_bytes;
+  /* BlockBitPacking blocks / FOR frames */
+  uint32_t seg_size, seg_count, seg_first, seg_last;
+  uint8_t* seg_width; uint8_t* seg_base; uint64_t* seg_off;   /* per segment: bit width, baseline (es bytes), offset */
+  uint64_t payload_bytes;
 };
 
 static void orc_fail(orc_ctx* c, const char* fmt, ...) {
@@ -658,9 +671,140 @@ static void varint_init(orc_enc* e) {
   varint_reset(e);
 }
 
+/* ---- BlockBitPacking / FOR ---------------------------------------------------- */
+/* `w` bits at bit position `bit` of an LSB-first stream, read byte-wise inside [p, p+bytes). */
+static uint64_t bits_at(orc_ctx* c, const uint8_t* p, uint64_t bytes, uint64_t bit, int w) {
+  if (w == 0) return 0;
+  ORC_CHECK(c, (bit + (uint64_t)w + 7) / 8 <= bytes, "packed segment beyond end of the payload");
+  uint64_t v = 0; int got = 0; uint64_t byte = bit >> 3; int sh = (int)(bit & 7);
+  while (got < w) {
+    const uint64_t chunk = (uint64_t)(p[byte] >> sh);
+    v |= got < 64 ? chunk << got : 0;
+    got += 8 - sh; sh = 0; ++byte;
+  }
+  return w == 64 ? v : v & ((1ull << w) - 1);
+}
+static uint32_t seg_index(const orc_enc* e, uint32_t row) {   /* blockIndex / frameIndex */
+  if (row < e->seg_first) return 0;
+  return 1 + (row - e->seg_first) / e->seg_size;
+}
+static uint32_t seg_row_offset(const orc_enc* e, uint32_t s) { return s == 0 ? 0 : e->seg_first + (s - 1) * e->seg_size; }
+/* varint header field; the oracle adds the bound the reference leaves out */
+static uint32_t header_varint(orc_enc* e, const uint8_t** p) {
+  const uint8_t* end = e->data + e->size;
+  const uint8_t* q = *p;
+  int n = 0;
+  while (q < end && n < 5 && (*q & 128)) { ++q; ++n; }
+  ORC_CHECK(e->ctx, q < end, "header field beyond end of encoding");
+  return read_varint32(p);
+}
+static void seg_reset(orc_enc* e) { e->row = 0; }
+static void seg_skip(orc_enc* e, uint32_t n) { e->row += n; }
+static void seg_materialize(orc_enc* e, uint32_t n, void* buffer) {
+  /* BlockBitPackingEncoding.h:746-784,856-874; ForEncoding.h:398-529 */
+  orc_ctx* c = e->ctx;
+  uint8_t* out = (uint8_t*)buffer;
+  ORC_CHECK(c, (uint64_t)e->row + n <= e->rows, "Decoding past end of encoding");
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint32_t row = e->row + i;
+    const uint32_t s = seg_index(e, row);
+    ORC_CHECK(c, s < e->seg_count, "row beyond the last block");
+    const uint32_t in_seg = row - seg_row_offset(e, s);
+    const int w = e->seg_width[s];
+    uint64_t base = 0; memcpy(&base, e->seg_base + (size_t)s * e->es, (size_t)e->es);
+    uint64_t v;
+    if (e->etype == ET_BLOCKBITPACKING) {
+      if (w == 255) {   /* raw block */
+        ORC_CHECK(c, e->seg_off[s] + ((uint64_t)in_seg + 1) * e->es <= e->payload_bytes, "raw block beyond end of the payload");
+        v = ld_le(e->payload + e->seg_off[s] + (uint64_t)in_seg * e->es, e->es);
+      } else {
+        ORC_CHECK(c, w < 8 * e->es, "block bit width %d too wide for a %d-byte type", w, e->es);
+        ORC_CHECK(c, e->seg_off[s] <= e->payload_bytes, "block offset beyond end of the payload");
+        v = bits_at(c, e->payload + e->seg_off[s], e->payload_bytes - e->seg_off[s], (uint64_t)in_seg * (uint64_t)w, w) + base;
+      }
+    } else {
+      ORC_CHECK(c, w <= 64, "frame bit width %d", w);
+      v = bits_at(c, e->payload, e->payload_bytes, e->seg_off[s] + (uint64_t)in_seg * (uint64_t)w, w) + base;
+    }
+    st_le(out + (uint64_t)i * e->es, v, e->es);
+  }
+  e->row += n;
+}
+static const uint8_t* seg_child(orc_enc* e, const uint8_t* p, uint32_t rows, int es, void* dst) {
+  /* varint size + nested encoding, materialised whole (readMetadataStream, BlockBitPackingEncoding.h:698-710) */
+  orc_ctx* c = e->ctx;
+  const uint8_t* end = e->data + e->size;
+  const uint32_t size = header_varint(e, &p);
+  ORC_CHECK(c, p <= end && size <= (uint64_t)(end - p), "metadata stream beyond end");
+  orc_enc* ch = orc_create_in(c, p, size);
+  ORC_CHECK(c, ch->es == es && ch->dtype != DT_BOOL && ch->dtype != DT_STRING, "metadata stream has the wrong element size");
+  ORC_CHECK(c, ch->rows >= rows, "metadata stream shorter than the block count");
+  ch->materialize(ch, rows, dst);
+  return p + size;
+}
+static void seg_alloc(orc_enc* e) {
+  e->seg_width = (uint8_t*)orc_xmalloc(e->ctx, e->seg_count);
+  e->seg_base = (uint8_t*)orc_xmalloc(e->ctx, (size_t)e->seg_count * e->es);
+  e->seg_off = (uint64_t*)orc_xmalloc(e->ctx, (size_t)e->seg_count * 8);
+}
+static void seg_geometry(orc_enc* e, const char* what) {
+  orc_ctx* c = e->ctx;
+  ORC_CHECK(c, e->seg_size > 0 && e->seg_count > 0 && e->rows > 0, "%s needs rows, a block size and blocks", what);
+  ORC_CHECK(c, e->seg_first > 0 && e->seg_first <= e->seg_size && e->seg_first <= e->rows, "%s first block rows out of range", what);
+  const uint64_t expect = e->rows <= e->seg_first ? 1 : 1 + ((uint64_t)(e->rows - e->seg_first) + e->seg_size - 1) / e->seg_size;
+  ORC_CHECK(c, e->seg_count == expect, "%s block count mismatch.", what);
+  e->seg_last = e->seg_count == 1 ? e->seg_first : e->rows - e->seg_first - (e->seg_count - 2) * e->seg_size;
+}
+static void bbp_init(orc_enc* e) {  /* BlockBitPackingEncoding.h:311-348,660-696 */
+  orc_ctx* c = e->ctx;
+  ORC_CHECK(c, e->dtype != DT_BOOL && e->dtype != DT_STRING, "BlockBitPacking needs a numeric type");
+  const uint8_t* p = e->data + e->prefix; const uint8_t* end = e->data + e->size;
+  ORC_CHECK(c, p + 3 <= end, "BlockBitPacking header beyond end");
+  ORC_CHECK(c, p[0] == 0, "compressed BlockBitPacking payload not supported by the oracle");
+  ++p;
+  e->seg_size = (uint16_t)header_varint(e, &p);
+  e->seg_count = (uint16_t)header_varint(e, &p);
+  ORC_CHECK(c, e->seg_size > 0 && e->seg_size <= 1024 && e->seg_count > 0 && e->rows > 0, "BlockBitPacking block size / count out of range");
+  seg_alloc(e);
+  uint32_t* off32 = (uint32_t*)orc_xmalloc(c, (size_t)e->seg_count * 4);
+  p = seg_child(e, p, e->seg_count, e->es, e->seg_base);
+  p = seg_child(e, p, e->seg_count, 1, e->seg_width);
+  p = seg_child(e, p, e->seg_count, 4, off32);
+  for (uint32_t i = 0; i < e->seg_count; ++i) e->seg_off[i] = off32[i];
+  free(off32);
+  e->seg_first = header_varint(e, &p);
+  seg_geometry(e, "BlockBitPacking");
+  e->payload = p; e->payload_bytes = (uint64_t)(end - p);
+  e->reset = seg_reset; e->skip = seg_skip; e->materialize = seg_materialize;
+}
+static void for_init(orc_enc* e) {  /* ForEncoding.h:174-196,316-383 */
+  orc_ctx* c = e->ctx;
+  ORC_CHECK(c, e->dtype >= DT_INT8 && e->dtype <= DT_UINT64, "FOR needs an integer type");
+  const uint8_t* p = e->data + e->prefix; const uint8_t* end = e->data + e->size;
+  ORC_CHECK(c, p + 4 <= end, "FOR header beyond end");
+  ORC_CHECK(c, p[0] == 0, "compressed FOR payload not supported by the oracle");
+  ++p;
+  e->seg_size = header_varint(e, &p);
+  e->seg_count = header_varint(e, &p);
+  e->seg_first = header_varint(e, &p);
+  seg_geometry(e, "FOR");
+  seg_alloc(e);
+  p = seg_child(e, p, e->seg_count, 1, e->seg_width);
+  p = seg_child(e, p, e->seg_count, e->es, e->seg_base);
+  p = seg_child(e, p, e->seg_count, 8, e->seg_off);
+  const uint32_t packed = header_varint(e, &p);
+  ORC_CHECK(c, p <= end && packed <= (uint64_t)(end - p), "FOR packed data beyond end");
+  e->payload = p; e->payload_bytes = packed;
+  e->reset = seg_reset; e->skip = seg_skip; e->materialize = seg_materialize;
+}
+
 /* ---- factory ----------------------------------------------------------------- */
 static void ctx_release(orc_ctx* c) {
-  for (size_t i = 0; i < c->nencs; ++i) { free(c->encs[i]->bufv); free(c->encs[i]->alphabet); free(c->encs[i]); }
+  for (size_t i = 0; i < c->nencs; ++i) {
+    free(c->encs[i]->bufv); free(c->encs[i]->alphabet);
+    free(c->encs[i]->seg_width); free(c->encs[i]->seg_base); free(c->encs[i]->seg_off);
+    free(c->encs[i]);
+  }
   for (size_t i = 0; i < c->nallocs; ++i) free(c->allocs[i]);
   free(c->encs); free(c->allocs);
   c->encs = NULL; c->allocs = NULL; c->nencs = c->nallocs = 0;
@@ -677,6 +821,8 @@ static orc_enc* orc_create_in(orc_ctx* c, const uint8_t* data, uint64_t size) {
     case ET_VARINT: varint_init(e); break;
     case ET_CONSTANT: const_init(e); break;
     case ET_MAINLYCONSTANT: mc_init(e); break;
+    case ET_BLOCKBITPACKING: bbp_init(e); break;
+    case ET_FOR: for_init(e); break;
     default: {
       orc_fail(c, "Trying to deserialize invalid EncodingType:%d -- garbage input?", (int)e->etype);
     }
@@ -720,6 +866,18 @@ int orc_materialize_bools_as_bits(orc_handle* h, uint32_t n, uint64_t* buffer, i
   ORC_GUARD(h, -1);
   ORC_CHECK(&h->ctx, h->root->bools_as_bits != NULL, "materializeBoolsAsBits not implemented");
   h->root->bools_as_bits(h->root, n, buffer, begin);
+  return 0;
+}
+
+/* EncodingView::read (encodings/views/EncodingView.h:38-41,92-95): rows
+ * [offset, offset+length) of the stream, independent of any cursor. */
+int orc_view_read(orc_handle* h, uint32_t offset, uint32_t length, void* buffer) {
+  ORC_GUARD(h, -1);
+  orc_enc* e = h->root;
+  ORC_CHECK(&h->ctx, offset <= e->rows && length <= e->rows - offset, "read range beyond the row count");
+  e->reset(e);
+  e->skip(e, offset);
+  e->materialize(e, length, buffer);
   return 0;
 }
 

@@ -49,6 +49,8 @@ def lib():
         L.orc_skip.argtypes = [vp, u32]
         L.orc_materialize.restype = i32
         L.orc_materialize.argtypes = [vp, u32, vp]
+        L.orc_view_read.restype = i32
+        L.orc_view_read.argtypes = [vp, u32, u32, vp]
         L.orc_materialize_bools_as_bits.restype = i32
         L.orc_materialize_bools_as_bits.argtypes = [vp, u32, vp, i32]
         L.orc_materialize_nullable.restype = u32
@@ -129,6 +131,14 @@ class Encoding:
             return self._flatten(sv, n)
         out = np.empty(n, dtype=self._elem_dtype())
         if lib().orc_materialize(self._h, n, _ptr(out)):
+            self._err()
+        return out
+
+    def read(self, offset: int, length: int):
+        """EncodingView::read (encodings/views/EncodingView.h:38-41): rows
+        [offset, offset+length) whatever the cursor; numeric / bool only."""
+        out = np.empty(length, dtype=self._elem_dtype())
+        if lib().orc_view_read(self._h, offset, length, _ptr(out)):
             self._err()
         return out
 

@@ -21,7 +21,8 @@ def random_numeric_spec(rng, dtype: int, depth: int):
     if depth <= 0:
         kind = leaves[int(rng.integers(0, len(leaves)))]
     else:
-        kind = (leaves + ["rle", "dictionary", "mainly_constant", "rle", "dictionary"])[int(rng.integers(0, len(leaves) + 5))]
+        inner = ["rle", "dictionary", "mainly_constant", "rle", "dictionary", "block"] + (["for"] if dtype in W.INTEGER_TYPES else [])
+        kind = (leaves + inner)[int(rng.integers(0, len(leaves) + len(inner)))]
     if kind == "trivial":
         return E.Trivial()
     if kind == "fbw":
@@ -32,6 +33,15 @@ def random_numeric_spec(rng, dtype: int, depth: int):
         return E.RLE(lengths=random_numeric_spec(rng, W.UINT32, depth - 1), values=random_numeric_spec(rng, dtype, depth - 1))
     if kind == "dictionary":
         return E.Dictionary(alphabet=random_numeric_spec(rng, dtype, depth - 1), indices=random_numeric_spec(rng, W.UINT32, depth - 1))
+    if kind in ("block", "for"):  # per-segment arrays: same-width unsigned baselines, uint8 widths, uint32 / uint64 offsets
+        unsigned = {1: W.UINT8, 2: W.UINT16, 4: W.UINT32, 8: W.UINT64}[es]
+        size = int(rng.integers(1, 300))
+        first = int(rng.integers(1, size + 1)) if rng.random() < 0.3 else None
+        meta = [random_numeric_spec(rng, t, depth - 1) for t in (unsigned, W.UINT8, W.UINT32 if kind == "block" else W.UINT64)]
+        if kind == "block":
+            return E.BlockBitPacking(baselines=meta[0], bit_widths=meta[1], offsets=meta[2], block_size=size, first_block_rows=first)
+        return E.FOR(references=meta[0], bit_widths=meta[1], bit_offsets=meta[2], frame_size=size, first_frame_rows=first,
+                     exact_bits=bool(rng.integers(0, 2)))
     return E.MainlyConstant(is_common=random_bool_spec(rng, depth - 1), other=random_numeric_spec(rng, dtype, depth - 1))
 
 

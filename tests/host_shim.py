@@ -54,6 +54,18 @@ def lib():
         L.nblh_dictionary_size.argtypes = [vp, C.POINTER(u32)]
         L.nblh_dictionary_entries.argtypes = [vp, C.POINTER(vp)]
         L.nblh_materialize_indices.argtypes = [vp, u32, vp]
+        L.nblh_supports_encoding_view.restype = i32
+        L.nblh_supports_encoding_view.argtypes = [i32]
+        L.nblh_view_create.restype = vp
+        L.nblh_view_create.argtypes = [vp, vp, u64]
+        L.nblh_view_free.argtypes = [vp]
+        L.nblh_view_row_count.restype = u32
+        L.nblh_view_row_count.argtypes = [vp]
+        for f in ("nblh_view_encoding_type", "nblh_view_data_type"):
+            getattr(L, f).restype = i32
+            getattr(L, f).argtypes = [vp]
+        L.nblh_view_read.argtypes = [vp, u32, u32, vp]
+        L.nblh_view_read_at.argtypes = [vp, u32, vp]
         L.nblh_stripe_create.restype = vp
         L.nblh_stripe_create.argtypes = [vp, C.POINTER(C.c_char_p), vp, u32]
         L.nblh_stripe_free.argtypes = [vp]
@@ -187,6 +199,51 @@ class HostEncoding:
         _chk(lib().nblh_materialize_nullable(self._h, n, _p(buffer), _p(nulls), C.byref(req), _p(scatter), scatter_size,
                                              offset, C.byref(nn)))
         return nn.value, bool(req.value)
+
+
+class HostEncodingView:
+    """GpuEncodingFactory::createEncodingView: cursor-free reads of one stream."""
+
+    def __init__(self, factory: Factory, data):
+        self._data = np.frombuffer(bytes(data), dtype=np.uint8).copy()
+        self._factory = factory
+        self._h = lib().nblh_view_create(factory._h, _p(self._data), self._data.size)
+        if not self._h:
+            _chk(-1)
+        self.row_count = lib().nblh_view_row_count(self._h)
+        self.data_type = lib().nblh_view_data_type(self._h)
+        self.encoding_type = lib().nblh_view_encoding_type(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().nblh_view_free(self._h)
+            self._h = None
+
+    def _out(self, n):
+        if self.data_type == W.STRING:
+            return np.zeros(2 * n, dtype=np.uint64)
+        return np.empty(n, dtype=np.uint8 if self.data_type == W.BOOL else W.physical_dtype(self.data_type))
+
+    def _strings(self, sv, n):
+        total = lib().nblh_sv_total(_p(sv), n)
+        lengths = np.zeros(n, dtype=np.uint32)
+        blob = np.zeros(max(int(total), 1), dtype=np.uint8)
+        lib().nblh_sv_flatten(_p(sv), n, _p(lengths), _p(blob))
+        return lengths, blob[: int(total)]
+
+    def read(self, offset, length):
+        out = self._out(length)
+        _chk(lib().nblh_view_read(self._h, offset, length, _p(out)))
+        return self._strings(out, length) if self.data_type == W.STRING else out
+
+    def read_at(self, index):
+        out = self._out(1)
+        _chk(lib().nblh_view_read_at(self._h, index, _p(out)))
+        return self._strings(out, 1) if self.data_type == W.STRING else out[0]
+
+
+def supports_encoding_view(encoding_type: int) -> bool:
+    return bool(lib().nblh_supports_encoding_view(int(encoding_type)))
 
 
 class StripeDecoder:

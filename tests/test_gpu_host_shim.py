@@ -246,3 +246,68 @@ def test_device_resident_batch(factory, oracle):
     host = batch.to_host()
     for enc, lay in zip(encs, batch.layouts):
         assert_chunk_equal(slice_chunk(host, lay), oracle_chunk(oracle, enc), "device batch")
+
+
+def test_encoding_view_random_access(factory, oracle):
+    """createEncodingView: readAt / range read are cursor free and agree with the
+    oracle's decode for every encoding the reference has a view for
+    (encodings/views/EncodingViewFactory.cpp:47-135, tests/EncodingViewTest.cpp)."""
+    import host_shim
+
+    rng = np.random.default_rng(41)
+    n = 3000
+    runs = np.repeat(rng.integers(0, 1 << 30, n // 9 + 1), 9)[:n].astype(np.int64)
+    cases = [(spec, runs, W.INT64) for spec in (E.Trivial(), E.FixedBitWidth(exact_bits=True), E.RLE(), E.Dictionary(),
+                                                E.MainlyConstant(), E.BlockBitPacking(block_size=100), E.FOR())]
+    cases.append((E.Constant(), np.full(n, 7, dtype=np.int32), W.INT32))
+    cases.append((E.SparseBool(), rng.random(n) < 0.03, W.BOOL))
+    cases.append((E.Trivial(), rng.random(n) < 0.5, W.BOOL))
+    cases.append((E.BlockBitPacking(), rng.integers(0, 2**32, n, dtype=np.uint64).astype(np.uint32).view(np.float32), W.FLOAT))
+    for spec, data, dtype in cases:
+        enc = E.encode(spec, data, dtype)
+        view = host_shim.HostEncodingView(factory, enc)
+        want = oracle.Encoding(enc).materialize(n)
+        assert view.row_count == n and view.data_type == dtype and view.encoding_type == enc[0]
+        assert host_shim.supports_encoding_view(enc[0])
+        for _ in range(20):
+            off = int(rng.integers(0, n + 1))
+            length = int(rng.integers(0, n - off + 1))
+            assert np.array_equal(view.read(off, length), want[off:off + length]), repr(spec)
+            i = int(rng.integers(0, n))
+            assert view.read_at(i) == want[i]
+        assert np.array_equal(view.read(0, n), oracle.Encoding(enc).read(0, n))
+        with pytest.raises(host_shim.HostError, match="beyond the row count"):
+            view.read(n - 1, 2)
+        with pytest.raises(host_shim.HostError, match="beyond the row count"):
+            view.read_at(n)
+    # strings: the view owns the bytes its string_views point into
+    alpha = random_strings(rng, 30)
+    col = alpha.take(rng.integers(0, 30, 500))
+    for spec in (E.Trivial(), E.Dictionary(), E.RLE(values=E.Trivial()), E.MainlyConstant(other=E.Trivial())):
+        view = host_shim.HostEncodingView(factory, E.encode(spec, col, W.STRING))
+        lens, blob = view.read(100, 50)
+        sub = col.take(np.arange(100, 150))
+        assert np.array_equal(lens, sub.lengths) and np.array_equal(blob, sub.blob)
+        lens, blob = view.read_at(499)
+        assert blob.tobytes() == col.to_list()[499]
+    # no view for Nullable / Varint, as in the reference
+    for enc in (E.encode(E.Varint(), runs, W.INT64),
+                E.encode_nullable(E.Nullable(), runs[:10], np.ones(10, dtype=bool), W.INT64)):
+        assert not host_shim.supports_encoding_view(enc[0])
+        with pytest.raises(host_shim.HostError, match="does not support EncodingView"):
+            host_shim.HostEncodingView(factory, enc)
+
+
+def test_block_encodings_through_the_host_layer(factory):
+    """Encoding contract (cursor, skip, scattered materialize) over BlockBitPacking / FOR chunks,
+    incl. compressed packed blocks inflated by the host pre-pass."""
+    pytest.importorskip("pyarrow")
+    rng = np.random.default_rng(43)
+    for dtype in (W.INT16, W.INT32, W.UINT64):
+        data = (np.repeat(rng.integers(0, 1000, 20), 100) + rng.integers(0, 9, 2000)).astype(W.physical_dtype(dtype))
+        for spec in (E.BlockBitPacking(block_size=128), E.FOR(), E.BlockBitPacking(compression="zstd"), E.FOR(compression="lz4")):
+            e = factory.create(E.encode(spec, data, dtype))
+            assert e.row_count == 2000 and e.data_type == dtype
+            check_materialize_patterns(e, phys(data, dtype), dtype, rng)
+            e.reset()
+            check_scattered_materialize(e, phys(data, dtype), dtype, rng)

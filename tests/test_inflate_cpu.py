@@ -22,9 +22,10 @@ def _with_compression(spec, codec):
     s = copy.deepcopy(spec)
 
     def walk(x):
-        if isinstance(x, (E.Trivial, E.FixedBitWidth)):
+        if isinstance(x, (E.Trivial, E.FixedBitWidth, E.BlockBitPacking, E.FOR)):
             x.compression = codec
-        for name in ("lengths", "values", "alphabet", "indices", "data", "nulls", "is_common", "other"):
+        for name in ("lengths", "values", "alphabet", "indices", "data", "nulls", "is_common", "other",
+                     "baselines", "bit_widths", "offsets", "references", "bit_offsets"):
             child = getattr(x, name, None)
             if child is not None and not isinstance(child, (int, bool)):
                 walk(child)
@@ -47,6 +48,10 @@ def _cases(rng):
     yield E.MainlyConstant(is_common=E.Trivial(), other=E.FixedBitWidth()), ints, W.INT64
     yield E.SparseBool(indices=E.Trivial()), bools, W.BOOL
     yield E.RLE(lengths=E.RLE(lengths=E.Trivial(), values=E.FixedBitWidth())), bools, W.BOOL
+    # block encodings: compressed packed blocks, and varint-sized children whose size changes when inflated
+    yield E.BlockBitPacking(block_size=64), ints, W.INT64
+    yield E.FOR(bit_widths=E.FixedBitWidth(), references=E.Trivial(), bit_offsets=E.Trivial(), frame_size=16), ints, W.INT64
+    yield E.RLE(lengths=E.FOR(frame_size=8), values=E.BlockBitPacking(block_size=32, offsets=E.FixedBitWidth())), ints, W.INT64
 
 
 @pytest.mark.parametrize("codec", ["zstd", "lz4"])
