@@ -76,6 +76,58 @@ def cpu_baseline(chunks, min_seconds=12.0):
     }
 
 
+def cpu_baseline_threads(chunks, threads, min_seconds=8.0):
+    """The same oracle on `threads` host threads, one chunk per task (chunks are
+    independent, as columns and stripes are for the reference's reader).  The
+    oracle calls run outside the GIL."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import oracle as O
+
+    lib = O.lib()
+    arrays = [np.frombuffer(enc, dtype=np.uint8) for _, enc in chunks]
+    es_of = {1: 1, 2: 1, 3: 2, 4: 2, 5: 4, 6: 4, 7: 8, 8: 8, 9: 4, 10: 8, 11: 1, 12: 16}
+    meta = [(int(np.frombuffer(enc[2:6], dtype=np.uint32)[0]), es_of[enc[1]]) for _, enc in chunks]
+    biggest = max(n * es for n, es in meta) + 64
+    deadline = [0.0]
+
+    def worker(t):
+        vals = np.zeros(biggest, dtype=np.uint8)
+        out = rows = 0
+        while True:
+            for i in range(t, len(arrays), threads):
+                if lib.orc_decode_all(arrays[i].ctypes.data, arrays[i].size, 0, vals.ctypes.data, None) == 0xFFFFFFFF:
+                    raise RuntimeError("oracle failed to decode a benchmark chunk")
+                out += meta[i][0] * meta[i][1]
+                rows += meta[i][0]
+            if time.perf_counter() >= deadline[0]:
+                return out, rows
+
+    t0 = time.perf_counter()
+    deadline[0] = t0 + min_seconds
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        parts = list(pool.map(worker, range(threads)))
+    dt = time.perf_counter() - t0
+    out_bytes, rows = sum(p[0] for p in parts), sum(p[1] for p in parts)
+    return {"value": round(out_bytes / dt / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "port",
+            "sample": f"{threads} threads, each looping over its share of the same {len(chunks)} chunks for {dt:.1f} s "
+                      f"({rows} rows, {out_bytes} decoded bytes)",
+            "rows_per_s": round(rows / dt)}
+
+
+def copy_ceiling(torch, device, nbytes=1 << 31, reps=10):
+    """In-run achievable HBM rate: a device-to-device copy of `nbytes` (bytes read + bytes written per second)."""
+    src = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize(device)
+    return 2 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
 def pcie_inclusive(dec, plan, torch, device, steps=5):
     """The same step with the host at both ends: H2D of the encoded bytes from
     pinned memory, decode, D2H of the decoded output into pinned memory.
@@ -247,6 +299,11 @@ def main():
             roofline["traffic_source"] = os.path.relpath(path, ROOT)
             break
     whole = (int(info.encoded_bytes) + decoded) / (sum(launch_ms) * 1e-3) / 1e9 if sum(launch_ms) > 0 else 0.0
+    if rank == 0:
+        # second denominator: what a plain device-to-device copy sustains on this GPU in this run
+        ceiling = copy_ceiling(torch, device)
+        roofline["copy_ceiling_gbs"] = round(ceiling, 1)
+        roofline["frac_of_copy_ceiling"] = round(achieved / ceiling, 4) if ceiling > 0 else None
 
     result = {
         "metric": "device-resident decoded GB/s (output bytes) per GPU and per 8xMI355X node",
@@ -306,7 +363,10 @@ def main():
         result["pcie_inclusive"] = pcie_inclusive(dec, plan, torch, device)
         result["pcie_pipelined"] = pcie_pipelined(plan, torch, device)
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(chunks)
+        result["cpu_baseline"] = cpu_baseline(chunks, min_seconds=10.0)
+        # the GPU box gives this job 16 host threads (OMP_NUM_THREADS is set to that share)
+        threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1), 16, len(chunks)))
+        result["cpu_baseline_all_cores"] = cpu_baseline_threads(chunks, threads)
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

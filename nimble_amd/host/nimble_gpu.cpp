@@ -670,10 +670,139 @@ class GpuStreamDecoder final : public Decoder {
   uint32_t remaining_ = 0;
 };
 
+// velox::bits::scatterBits in place: source bit k moves to the k-th set position
+// of `mask`, the other positions of [0, numTarget) become 0
+void scatterBitsInPlace(int64_t numSource, int64_t numTarget, void* bits, const void* mask) {
+  int64_t src = numSource - 1;
+  for (int64_t pos = numTarget - 1; pos >= 0; --pos) {
+    if (bitIsSet(mask, (uint64_t)pos)) {
+      const bool b = src >= 0 && bitIsSet(bits, (uint64_t)src);
+      --src;
+      b ? bitSet(bits, (uint64_t)pos) : bitClear(bits, (uint64_t)pos);
+    } else {
+      bitClear(bits, (uint64_t)pos);
+    }
+  }
+}
+
+class GpuChunkedDecoder final : public ChunkedDecoder {
+ public:
+  GpuChunkedDecoder(std::vector<std::unique_ptr<Encoding>>& chunks, bool decodeValuesWithNulls)
+      : chunks_(chunks), decodeValuesWithNulls_(decodeValuesWithNulls) {}
+
+  void skip(int64_t numValues) override {
+    if (numValues < 0) throw NimbleError(NBL_ERR_ARGUMENT, "negative skip");
+    while (numValues > 0) {
+      if (remaining_ == 0) loadNextChunk();
+      if (numValues < remaining_) {
+        cur().skip((uint32_t)numValues);
+        remaining_ -= numValues;
+        break;
+      }
+      numValues -= remaining_;
+      remaining_ = 0;
+    }
+  }
+
+  void nextBools(uint64_t* data, int64_t count, const uint64_t* incomingNulls) override {
+    if (decodeValuesWithNulls_) {
+      if (nullableValues_.size() < (size_t)count) nullableValues_.assign((size_t)count, 0);
+      decodeNullable(data, nullableValues_.data(), count, incomingNulls);
+      return;
+    }
+    const int64_t total = incomingNulls ? (int64_t)countBits(incomingNulls, 0, (uint64_t)count) : count;
+    for (int64_t i = 0; i < total;) {
+      if (remaining_ == 0) {
+        loadNextChunk();
+        if (cur().dataType() != DataType::Bool) throw NimbleError(NBL_ERR_ARGUMENT, "nextBools on a non-bool stream");
+      }
+      const int64_t n = std::min(total - i, remaining_);
+      cur().materializeBoolsAsBits((uint32_t)n, data, (int)i);
+      remaining_ -= n;
+      i += n;
+    }
+    if (incomingNulls) scatterBitsInPlace(total, count, data, incomingNulls);
+  }
+
+  void nextIndices(int32_t* data, int64_t count, const uint64_t* incomingNulls) override {
+    std::vector<uint64_t> nulls;
+    if (incomingNulls) nulls.assign(((size_t)count + 63) / 64 + 1, 0);
+    decodeNullable(incomingNulls ? nulls.data() : nullptr, data, count, incomingNulls);
+  }
+
+  void decodeNullable(uint64_t* nulls, void* data, int64_t count, const uint64_t* incomingNulls) override {
+    const int64_t total = incomingNulls ? (int64_t)countBits(incomingNulls, 0, (uint64_t)count) : count;
+    auto getNulls = [&]() -> void* {
+      if (!nulls) throw NimbleError(NBL_ERR_ARGUMENT, "the stream has nulls but no null buffer was passed");
+      return nulls;
+    };
+    if (incomingNulls) {
+      if (total == 0) {
+        if (nulls) fillBits(nulls, 0, (uint64_t)count, false);
+        return;
+      }
+      uint32_t offset = 0;
+      for (int64_t i = 0; i < total;) {
+        if (remaining_ == 0) loadNextChunk();
+        const int64_t n = std::min(total - i, remaining_);
+        const uint32_t endOffset = findSetBit(incomingNulls, offset, (uint32_t)count, (uint32_t)n + 1);
+        Bitmap local{incomingNulls, endOffset};
+        const uint32_t nonNull = cur().materializeNullable((uint32_t)n, data, getNulls, &local, offset);
+        if (nulls && nonNull == endOffset - offset) fillBits(nulls, offset, endOffset, true);
+        remaining_ -= n;
+        i += n;
+        offset = endOffset;
+      }
+    } else {
+      for (int64_t i = 0; i < total;) {
+        if (remaining_ == 0) loadNextChunk();
+        const int64_t n = std::min(total - i, remaining_);
+        const uint32_t nonNull = cur().materializeNullable((uint32_t)n, data, getNulls, nullptr, (uint32_t)i);
+        if (nulls && nonNull == (uint32_t)n) fillBits(nulls, (uint64_t)i, (uint64_t)(i + n), true);
+        remaining_ -= n;
+        i += n;
+      }
+    }
+  }
+
+  const uint32_t* preloadedValues() const override {
+    if (!decodeValuesWithNulls_) throw NimbleError(NBL_ERR_ARGUMENT, "Only Array and Map types preload offset values with nulls");
+    return nullableValues_.data();
+  }
+  void ensureLoaded() override {
+    if (loaded_ && remaining_ != 0) return;
+    if (next_ < chunks_.size()) loadNextChunk();
+  }
+  const Encoding* currentEncoding() const override { return loaded_ ? chunks_[cur_].get() : nullptr; }
+  bool dictionaryConvertible() const override {
+    if (!loaded_) throw NimbleError(NBL_ERR_ARGUMENT, "dictionaryConvertible before ensureLoaded");
+    return chunks_[cur_]->dictionaryEnabled();
+  }
+  int64_t remainingValues() const override { return remaining_; }
+
+ private:
+  Encoding& cur() { return *chunks_[cur_]; }
+  void loadNextChunk() {  // ChunkedDecoder.cpp:33-85 (the chunk itself was decoded with the stripe)
+    if (next_ >= chunks_.size()) throw NimbleError(NBL_ERR_CORRUPT, "Failed to read chunk header");
+    cur_ = next_++;
+    loaded_ = true;
+    chunks_[cur_]->reset();
+    remaining_ = chunks_[cur_]->rowCount();
+    if (remaining_ == 0) throw NimbleError(NBL_ERR_CORRUPT, "Empty chunk");
+  }
+  std::vector<std::unique_ptr<Encoding>>& chunks_;
+  const bool decodeValuesWithNulls_;
+  size_t cur_ = 0, next_ = 0;
+  bool loaded_ = false;
+  int64_t remaining_ = 0;
+  std::vector<uint32_t> nullableValues_;
+};
+
 }  // namespace
 
 struct GpuStripeDecoder::Impl {
   std::vector<std::unique_ptr<GpuStreamDecoder>> streams;
+  std::vector<std::unique_ptr<GpuChunkedDecoder>> chunked;  // created on demand, one per stream
 };
 
 GpuStripeDecoder::GpuStripeDecoder(const GpuEncodingFactory& factory, const std::vector<std::string_view>& streams)
@@ -721,5 +850,11 @@ GpuStripeDecoder::GpuStripeDecoder(const GpuEncodingFactory& factory, const std:
 GpuStripeDecoder::~GpuStripeDecoder() = default;
 size_t GpuStripeDecoder::streamCount() const { return impl_->streams.size(); }
 Decoder& GpuStripeDecoder::decoder(size_t stream) { return *impl_->streams.at(stream); }
+ChunkedDecoder& GpuStripeDecoder::chunkedDecoder(size_t stream, bool decodeValuesWithNulls) {
+  if (impl_->chunked.size() < impl_->streams.size()) impl_->chunked.resize(impl_->streams.size());
+  auto& slot = impl_->chunked.at(stream);
+  if (!slot) slot = std::make_unique<GpuChunkedDecoder>(impl_->streams.at(stream)->chunks, decodeValuesWithNulls);
+  return *slot;
+}
 
 }  // namespace nimble_amd

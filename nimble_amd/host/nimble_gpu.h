@@ -6,6 +6,7 @@
 //   nimble::EncodingFactory ..... dwio/nimble/encodings/common/EncodingFactory.h:32-55
 //   nimble::Decoder ............. dwio/nimble/velox/Decoder.h:27-56
 //   ChunkedStreamDecoder ........ dwio/nimble/velox/ChunkedStreamDecoder.h:25-74
+//   nimble::ChunkedDecoder ...... dwio/nimble/velox/selective/ChunkedDecoder.h:54-311 (dense bulk entry points)
 //   nimble::EncodingView ........ dwio/nimble/encodings/views/EncodingView.h:32-104,
 //                                 encodings/views/EncodingViewFactory.h:36-46
 //
@@ -201,6 +202,32 @@ class Decoder {
   virtual const Encoding* encoding() const = 0;
 };
 
+// The selective reader's per-stream decoder, restricted to its dense bulk entry
+// points (no visitor, no filter): skip, nextBools, nextIndices,
+// decodeNullable<T> and the chunk inspection calls the dictionary-aware string
+// reader makes.  Bitmaps are uint64 words, LSB first, 1 = not null
+// (velox::bits::kNotNull).  `incomingNulls` marks the rows of the read range
+// that have a value in this stream; rows without one become nulls.
+class ChunkedDecoder {
+ public:
+  virtual ~ChunkedDecoder() = default;
+  // skipWithoutIndex (ChunkedDecoder.cpp:270-286)
+  virtual void skip(int64_t numValues) = 0;
+  // ChunkedDecoder.cpp:155-191.  With decodeValuesWithNulls the stream is a
+  // nullable uint32 stream: its NULL bitmap is the result, its values are kept
+  // for preloadedValues().
+  virtual void nextBools(uint64_t* data, int64_t count, const uint64_t* incomingNulls) = 0;
+  // ChunkedDecoder.cpp:193-206
+  virtual void nextIndices(int32_t* data, int64_t count, const uint64_t* incomingNulls) = 0;
+  // decodeNullable<T> (ChunkedDecoder.h:206-268); T is the stream's physical type
+  virtual void decodeNullable(uint64_t* nulls, void* data, int64_t count, const uint64_t* incomingNulls) = 0;
+  virtual const uint32_t* preloadedValues() const = 0;  // getPreloadedValues (:91-96)
+  virtual void ensureLoaded() = 0;                      // :289-298
+  virtual const Encoding* currentEncoding() const = 0;  // :301-303
+  virtual bool dictionaryConvertible() const = 0;       // :305-309
+  virtual int64_t remainingValues() const = 0;          // :311-313
+};
+
 // All streams of a stripe decoded in one batch; hands out one Decoder per
 // stream with ChunkedStreamDecoder semantics (velox/ChunkedStreamDecoder.cpp:75-205).
 // Mirrors VeloxReader::loadNextStripe creating every stream's decoder at once
@@ -213,6 +240,9 @@ class GpuStripeDecoder {
   ~GpuStripeDecoder();
   size_t streamCount() const;
   Decoder& decoder(size_t stream);
+  // The same decoded stream through the selective reader's interface.  A stream
+  // is read through ONE of the two objects: they share its chunks' row cursors.
+  ChunkedDecoder& chunkedDecoder(size_t stream, bool decodeValuesWithNulls = false);
 
  private:
   struct Impl;

@@ -183,6 +183,38 @@ int nblh_stripe_reset(void* s, uint32_t stream) {
   return guard([&] { static_cast<StripeHandle*>(s)->dec->decoder(stream).reset(); });
 }
 
+// selective reader's ChunkedDecoder over stream `stream` (created on first use with `with_nulls`)
+static ChunkedDecoder& CD(void* s, uint32_t stream, int with_nulls = 0) {
+  return static_cast<StripeHandle*>(s)->dec->chunkedDecoder(stream, with_nulls != 0);
+}
+int nblh_chunked_open(void* s, uint32_t stream, int decode_values_with_nulls) {
+  return guard([&] { CD(s, stream, decode_values_with_nulls); });
+}
+int nblh_chunked_skip(void* s, uint32_t stream, int64_t n) { return guard([&] { CD(s, stream).skip(n); }); }
+int nblh_chunked_next_bools(void* s, uint32_t stream, uint64_t* data, int64_t count, const uint64_t* incoming) {
+  return guard([&] { CD(s, stream).nextBools(data, count, incoming); });
+}
+int nblh_chunked_next_indices(void* s, uint32_t stream, int32_t* data, int64_t count, const uint64_t* incoming) {
+  return guard([&] { CD(s, stream).nextIndices(data, count, incoming); });
+}
+int nblh_chunked_decode_nullable(void* s, uint32_t stream, uint64_t* nulls, void* data, int64_t count, const uint64_t* incoming) {
+  return guard([&] { CD(s, stream).decodeNullable(nulls, data, count, incoming); });
+}
+int nblh_chunked_preloaded_values(void* s, uint32_t stream, const uint32_t** values) {
+  return guard([&] { *values = CD(s, stream).preloadedValues(); });
+}
+// *encoding_type = -1 when no chunk is loaded
+int nblh_chunked_state(void* s, uint32_t stream, int ensure_loaded, int64_t* remaining, int* encoding_type, int* dictionary_convertible) {
+  return guard([&] {
+    auto& d = CD(s, stream);
+    if (ensure_loaded) d.ensureLoaded();
+    *remaining = d.remainingValues();
+    const Encoding* e = d.currentEncoding();
+    *encoding_type = e ? (int)e->encodingType() : -1;
+    *dictionary_convertible = e ? (int)d.dictionaryConvertible() : 0;
+  });
+}
+
 // ---- device-resident batch ----------------------------------------------------
 void* nblh_decode_to_device(void* factory, const char* const* chunks, const uint64_t* sizes, uint32_t n) {
   DeviceBatch* b = nullptr;

@@ -34,6 +34,8 @@
  *   chunk framing ........... common/ChunkHeader.h:36-40,
  *                             velox/ChunkedStream.cpp:36-72
  *   multi-chunk stitching ... velox/ChunkedStreamDecoder.cpp:75-205
+ *   selective bulk reads .... velox/selective/ChunkedDecoder.h:206-268,
+ *                             velox/selective/ChunkedDecoder.cpp:155-206,270-286
  *
  * Third-party arithmetic the reference calls but does not vendor (velox @
  * 351b0a72f446c75e0bd0ad179063a7a02f8894fc: bits::fillBits / copyBits /
@@ -1048,6 +1050,96 @@ uint32_t orc_sd_next(orc_stream_decoder* d, uint32_t count, void* output, void* 
   }
   if (nulls_requested) *nulls_requested = requested;
   return non_null;
+}
+
+/* ---- selective reader's ChunkedDecoder: dense bulk entry points ----------------- */
+/* The same chunk cursor as above (loadNextChunk, selective/ChunkedDecoder.cpp:33-85,
+ * keeps one encoding and its remaining row count). */
+static uint32_t count_set_bits(const void* bits, uint64_t begin, uint64_t end) {
+  uint32_t n = 0; for (uint64_t i = begin; i < end; ++i) n += (uint32_t)bit_is_set(bits, i); return n;
+}
+/* velox::bits::scatterBits(numSource, numTarget, source, targetMask, target): source
+ * bit k goes to the k-th set position of the mask, other positions become 0; works in place. */
+static void scatter_bits(int64_t n_source, int64_t n_target, const void* source, const void* mask, void* target) {
+  int64_t src = n_source - 1;
+  for (int64_t pos = n_target - 1; pos >= 0; --pos) {
+    if (bit_is_set(mask, (uint64_t)pos)) {
+      const int b = src >= 0 ? bit_is_set(source, (uint64_t)src) : 0;
+      --src;
+      if (b) bit_set(target, (uint64_t)pos); else bit_clear(target, (uint64_t)pos);
+    } else {
+      bit_clear(target, (uint64_t)pos);
+    }
+  }
+}
+/* ChunkedDecoder::decodeNullable<T> (selective/ChunkedDecoder.h:206-268).  `nulls` may
+ * be NULL when the caller knows the stream holds no nulls.  0 on success. */
+int orc_cd_decode_nullable(orc_stream_decoder* d, void* nulls, void* data, int64_t count, const void* incoming) {
+  const int64_t total = incoming ? (int64_t)count_set_bits(incoming, 0, (uint64_t)count) : count;
+  if (incoming) {
+    if (total == 0) { if (nulls) fill_bits(nulls, 0, (uint64_t)count, 0); return 0; }
+    uint32_t offset = 0, end_offset = 0;
+    for (int64_t i = 0; i < total;) {
+      if (d->remaining == 0 && sd_ensure_loaded(d)) return -1;
+      const int64_t n = total - i < (int64_t)d->remaining ? total - i : (int64_t)d->remaining;
+      end_offset = orc_find_set_bit(incoming, offset, (uint32_t)count, (uint32_t)n + 1);
+      int req = 0;
+      const uint32_t nn = orc_materialize_nullable(d->enc, (uint32_t)n, data, nulls, &req, incoming, end_offset, offset);
+      if (nn == UINT32_MAX) { snprintf(d->err, sizeof d->err, "%s", d->enc->ctx.err); return -1; }
+      if (nulls && nn == end_offset - offset) fill_bits(nulls, offset, end_offset, 1);
+      d->remaining -= (uint32_t)n; i += n; offset = end_offset;
+    }
+  } else {
+    for (int64_t i = 0; i < total;) {
+      if (d->remaining == 0 && sd_ensure_loaded(d)) return -1;
+      const int64_t n = total - i < (int64_t)d->remaining ? total - i : (int64_t)d->remaining;
+      int req = 0;
+      const uint32_t nn = orc_materialize_nullable(d->enc, (uint32_t)n, data, nulls, &req, NULL, 0, (uint32_t)i);
+      if (nn == UINT32_MAX) { snprintf(d->err, sizeof d->err, "%s", d->enc->ctx.err); return -1; }
+      if (nulls && nn == (uint32_t)n) fill_bits(nulls, (uint64_t)i, (uint64_t)(i + n), 1);
+      d->remaining -= (uint32_t)n; i += n;
+    }
+  }
+  return 0;
+}
+/* ChunkedDecoder::nextBools (selective/ChunkedDecoder.cpp:155-191).  With
+ * decode_values_with_nulls the stream is a nullable uint32 stream whose NULLS are
+ * the result and whose values go to nullable_values[count] (getPreloadedValues). */
+int orc_cd_next_bools(orc_stream_decoder* d, uint64_t* data, int64_t count, const void* incoming,
+                      int decode_values_with_nulls, uint32_t* nullable_values) {
+  if (decode_values_with_nulls) return orc_cd_decode_nullable(d, data, nullable_values, count, incoming);
+  const int64_t total = incoming ? (int64_t)count_set_bits(incoming, 0, (uint64_t)count) : count;
+  for (int64_t i = 0; i < total;) {
+    if (d->remaining == 0) {
+      if (sd_ensure_loaded(d)) return -1;
+      if (d->enc->root->dtype != DT_BOOL) { snprintf(d->err, sizeof d->err, "nextBools on a non-bool stream"); return -1; }
+    }
+    const int64_t n = total - i < (int64_t)d->remaining ? total - i : (int64_t)d->remaining;
+    if (orc_materialize_bools_as_bits(d->enc, (uint32_t)n, data, (int)i)) { snprintf(d->err, sizeof d->err, "%s", d->enc->ctx.err); return -1; }
+    d->remaining -= (uint32_t)n; i += n;
+  }
+  if (incoming) scatter_bits(total, count, data, incoming, data);
+  return 0;
+}
+/* ChunkedDecoder::nextIndices (:193-206): uint32 values, nulls discarded. */
+int orc_cd_next_indices(orc_stream_decoder* d, int32_t* data, int64_t count, const void* incoming) {
+  void* nulls = incoming ? calloc(((size_t)count + 63) / 64 + 1, 8) : NULL;
+  const int rc = orc_cd_decode_nullable(d, nulls, data, count, incoming);
+  free(nulls);
+  return rc;
+}
+/* ChunkedDecoder::skipWithoutIndex (:270-286): whole chunks are dropped without touching their encoding. */
+int orc_cd_skip(orc_stream_decoder* d, int64_t n) {
+  while (n > 0) {
+    if (d->remaining == 0 && sd_ensure_loaded(d)) return -1;
+    if (n < (int64_t)d->remaining) {
+      if (orc_skip(d->enc, (uint32_t)n)) { snprintf(d->err, sizeof d->err, "%s", d->enc->ctx.err); return -1; }
+      d->remaining -= (uint32_t)n;
+      break;
+    }
+    n -= d->remaining; d->remaining = 0;
+  }
+  return 0;
 }
 
 /* ---- whole-chunk decode used by the CPU baseline ---------------------------- */

@@ -72,6 +72,15 @@ def lib():
         L.orc_sd_skip.argtypes = [vp, u32]
         L.orc_sd_next.restype = u32
         L.orc_sd_next.argtypes = [vp, u32, vp, vp, C.POINTER(i32), vp, u32]
+        i64 = C.c_int64
+        L.orc_cd_decode_nullable.restype = i32
+        L.orc_cd_decode_nullable.argtypes = [vp, vp, vp, i64, vp]
+        L.orc_cd_next_bools.restype = i32
+        L.orc_cd_next_bools.argtypes = [vp, vp, i64, vp, i32, vp]
+        L.orc_cd_next_indices.restype = i32
+        L.orc_cd_next_indices.argtypes = [vp, vp, i64, vp]
+        L.orc_cd_skip.restype = i32
+        L.orc_cd_skip.argtypes = [vp, i64]
         L.orc_decode_all.restype = u32
         L.orc_decode_all.argtypes = [u8p, u64, i32, vp, vp]
         _lib = L
@@ -246,3 +255,37 @@ class StreamDecoder:
         if r == 0xFFFFFFFF:
             self._err()
         return r, bool(req.value)
+
+
+class ChunkedDecoder(StreamDecoder):
+    """Dense bulk entry points of the selective reader's ChunkedDecoder
+    (velox/selective/ChunkedDecoder.h:78-90,206-268).  Bitmaps are uint8 arrays,
+    LSB first, 1 = not null."""
+
+    def __init__(self, stream: bytes, varint_rows: bool = False, decode_values_with_nulls: bool = False):
+        super().__init__(stream, varint_rows)
+        self.decode_values_with_nulls = decode_values_with_nulls
+        self.preloaded_values = None
+
+    def decode_nullable(self, nulls, data: np.ndarray, count: int, incoming_nulls=None):
+        if lib().orc_cd_decode_nullable(self._h, _ptr(nulls) if nulls is not None else None, _ptr(data), count,
+                                        _ptr(incoming_nulls) if incoming_nulls is not None else None):
+            self._err()
+
+    def next_bools(self, data: np.ndarray, count: int, incoming_nulls=None):
+        assert data.dtype == np.uint64
+        if self.decode_values_with_nulls:
+            self.preloaded_values = np.zeros(count, dtype=np.uint32)
+        if lib().orc_cd_next_bools(self._h, _ptr(data), count, _ptr(incoming_nulls) if incoming_nulls is not None else None,
+                                   int(self.decode_values_with_nulls),
+                                   _ptr(self.preloaded_values) if self.decode_values_with_nulls else None):
+            self._err()
+
+    def next_indices(self, data: np.ndarray, count: int, incoming_nulls=None):
+        assert data.dtype in (np.int32, np.uint32)
+        if lib().orc_cd_next_indices(self._h, _ptr(data), count, _ptr(incoming_nulls) if incoming_nulls is not None else None):
+            self._err()
+
+    def skip_values(self, n: int):
+        if lib().orc_cd_skip(self._h, n):
+            self._err()

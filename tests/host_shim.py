@@ -72,6 +72,14 @@ def lib():
         L.nblh_stripe_next.argtypes = [vp, u32, u32, vp, vp, C.POINTER(i32), vp, u32, C.POINTER(u32), C.POINTER(u32)]
         L.nblh_stripe_skip.argtypes = [vp, u32, u32]
         L.nblh_stripe_reset.argtypes = [vp, u32]
+        i64 = C.c_int64
+        L.nblh_chunked_open.argtypes = [vp, u32, i32]
+        L.nblh_chunked_skip.argtypes = [vp, u32, i64]
+        L.nblh_chunked_next_bools.argtypes = [vp, u32, vp, i64, vp]
+        L.nblh_chunked_next_indices.argtypes = [vp, u32, vp, i64, vp]
+        L.nblh_chunked_decode_nullable.argtypes = [vp, u32, vp, vp, i64, vp]
+        L.nblh_chunked_preloaded_values.argtypes = [vp, u32, C.POINTER(vp)]
+        L.nblh_chunked_state.argtypes = [vp, u32, i32, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32)]
         L.nblh_decode_to_device.restype = vp
         L.nblh_decode_to_device.argtypes = [vp, C.POINTER(C.c_char_p), vp, u32]
         L.nblh_device_batch_free.argtypes = [vp]
@@ -266,6 +274,11 @@ class StripeDecoder:
     def stream(self, i):
         return _StreamView(self, i)
 
+    def chunked(self, i, decode_values_with_nulls=False):
+        """The stream through the selective reader's ChunkedDecoder interface."""
+        _chk(lib().nblh_chunked_open(self._h, i, int(decode_values_with_nulls)))
+        return _ChunkedView(self, i, decode_values_with_nulls)
+
 
 class _StreamView:
     def __init__(self, stripe, idx):
@@ -285,6 +298,37 @@ class _StreamView:
                                     scatter_size, C.byref(nn), C.byref(nb_)))
         self.last_string_buffers = nb_.value
         return nn.value, bool(req.value)
+
+
+class _ChunkedView:
+    """Same Python surface as oracle.oracle.ChunkedDecoder."""
+
+    def __init__(self, stripe, idx, decode_values_with_nulls):
+        self._s, self._i = stripe, idx
+        self.decode_values_with_nulls = decode_values_with_nulls
+        self.preloaded_values = None
+
+    def decode_nullable(self, nulls, data, count, incoming_nulls=None):
+        _chk(lib().nblh_chunked_decode_nullable(self._s._h, self._i, _p(nulls), _p(data), count, _p(incoming_nulls)))
+
+    def next_bools(self, data, count, incoming_nulls=None):
+        _chk(lib().nblh_chunked_next_bools(self._s._h, self._i, _p(data), count, _p(incoming_nulls)))
+        if self.decode_values_with_nulls:
+            p = C.c_void_p()
+            _chk(lib().nblh_chunked_preloaded_values(self._s._h, self._i, C.byref(p)))
+            self.preloaded_values = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(max(count, 1),))[:count].copy()
+
+    def next_indices(self, data, count, incoming_nulls=None):
+        _chk(lib().nblh_chunked_next_indices(self._s._h, self._i, _p(data), count, _p(incoming_nulls)))
+
+    def skip_values(self, n):
+        _chk(lib().nblh_chunked_skip(self._s._h, self._i, n))
+
+    def state(self, ensure_loaded=False):
+        """(remaining values, encoding type or -1, dictionaryConvertible)"""
+        rem, et, dc = C.c_int64(), C.c_int(), C.c_int()
+        _chk(lib().nblh_chunked_state(self._s._h, self._i, int(ensure_loaded), C.byref(rem), C.byref(et), C.byref(dc)))
+        return rem.value, et.value, bool(dc.value)
 
 
 class Tablet:
