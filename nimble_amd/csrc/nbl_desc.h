@@ -87,6 +87,7 @@ enum NodeFlags : uint32_t {
   NF_WRITE_NULLS = 1u << 1,  // also emit the selection bitmap to out (Nullable root)
   NF_SPARSE_VALUE = 1u << 2, // SparseBool: listed positions are 1
   NF_FIRST_TRUE = 1u << 3,   // RLE<bool>: first run is true
+  NF_DICT_VALUES = 1u << 5,  // K_SELECT_SCATTER: c1 holds dictionary indices (uint32), c0 the alphabet; gather inline
   NF_FRAME_BITS = 1u << 4,   // K_FRAME_UNPACK: FOR (u64 bit offsets, no raw marker) instead of
                              // BlockBitPacking (u32 byte offsets, width 255 = raw block)
 };

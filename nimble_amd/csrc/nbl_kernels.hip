@@ -1109,10 +1109,66 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
     }
     return;
   }
+  const uint32_t last = n - 1;
+  if constexpr (ES >= 4) if (nd.flags & NF_DICT_VALUES) {  // the planner fuses 4- and 8-byte rows only
+    // The values child is a Dictionary whose gather is done here: c1 = its uint32
+    // indices (staged like any values), c0 = its alphabet as a plain element
+    // array.  The gathered rows never exist as an intermediate column.
+    const uint32_t A = nd.c0.rows;
+    const Reader<RK_PTR, ES> alpha(nd.c0, a);
+    bool bad = A == 0;
+    const uint32_t amax = A ? A - 1 : 0;
+    with_reader<4>(nd.c1, a, [&](auto rd) {
+      const auto idxs = rd.stage(base, n, smem);
+      write_nulls();
+      uint32_t total;
+      const uint32_t ex = block_excl_scan((uint32_t)__popcll(word), tmp, total);
+      if (threadIdx.x < W) { s_bits[threadIdx.x] = word; s_pref[threadIdx.x] = ex; }
+      __syncthreads();
+      constexpr uint32_t IB = ES == 8 ? 4 : 2;  // rounds whose gathers are in flight together (8 rows)
+#pragma unroll
+      for (uint32_t ib = 0; ib < 4; ib += IB) {
+        uint32_t ix[IB][V], sel[IB];
+#pragma unroll
+        for (uint32_t u = 0; u < IB; ++u) {
+          const uint32_t q0 = ((ib + u) * kBlock + threadIdx.x) * V;
+          const uint32_t qc = q0 < tile_rows ? q0 : 0;  // lanes past the tile repeat row 0 and store nothing
+          const uint64_t wd = s_bits[qc >> 6];
+          const uint32_t b = qc & 63;
+          uint32_t r = s_pref[qc >> 6] + (uint32_t)__popcll(wd & ((1ull << b) - 1ull));
+          const uint32_t bits = (uint32_t)(wd >> b);
+          sel[u] = bits & ((1u << V) - 1u);
+#pragma unroll
+          for (uint32_t j = 0; j < V; ++j) {
+            uint32_t i = idxs.at(r < last ? r : last);
+            if (i > amax) { bad = true; i = amax; }
+            ix[u][j] = i;
+            r += (bits >> j) & 1u;
+          }
+        }
+        T x[IB][V];
+#pragma unroll
+        for (uint32_t u = 0; u < IB; ++u)
+#pragma unroll
+          for (uint32_t j = 0; j < V; ++j) x[u][j] = A ? alpha.get(ix[u][j]) : fill;
+#pragma unroll
+        for (uint32_t u = 0; u < IB; ++u) {
+          const uint32_t q0 = ((ib + u) * kBlock + threadIdx.x) * V;
+          if (q0 >= tile_rows) continue;
+          Vec16<ES> o;
+          o.q = make_u32x4(0, 0, 0, 0);
+#pragma unroll
+          for (uint32_t j = 0; j < V; ++j) vec_set<ES>(o, j, ((sel[u] >> j) & 1u) ? x[u][j] : fill);
+          store_vec<ES>(dst, q0, tile_rows, o);
+        }
+      }
+    });
+    if (bad) atomicOr(a.status, ST_DICT_INDEX_RANGE);
+    return;
+  }
   // The n values are copied as raw bytes into LDS with aligned streaming loads
   // (each byte fetched once) while the bitmap words are still in flight; every
   // row then unpacks its value -- or takes the fill -- from LDS at its rank.
-  const uint32_t last = n - 1;
   with_reader<ES>(nd.c1, a, [&](auto rd) {
     const auto vals = rd.stage(base, n, smem);
     write_nulls();

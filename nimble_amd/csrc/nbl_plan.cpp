@@ -84,6 +84,10 @@ struct PNode {
   // string constants (Constant<string>, MainlyConstant<string> common value)
   uint64_t str_off = 0;      // arena offset of the string bytes
   uint32_t str_len = 0;
+  // Dictionary whose gather its Nullable / MainlyConstant parent performs: `ref`
+  // then names the uint32 indices and `alpha_ref` the alphabet element array
+  bool fused_gather = false;
+  ColRef alpha_ref{};
   // result
   ColRef ref{};              // how a consumer reads this node
   int ready = 0;             // level after which `ref` is valid
@@ -514,6 +518,14 @@ void nbl_plan::keep_dictionary_of(int dict_node, bool with_indices) {
 void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
   PNode& nn = nodes[idx];  // `nodes` no longer grows once parsing is done
   const uint32_t rows = nn.rows;
+  // A Dictionary of 4- or 8-byte rows (numbers, string views) directly under a
+  // Nullable / MainlyConstant is not expanded into a column of its own: the
+  // parent's rank scatter gathers from the alphabet itself, which saves writing
+  // and re-reading every non-null row.
+  if ((nn.enc == ET_NULLABLE || nn.enc == ET_MAINLYCONSTANT) && !nn.is_bool && nn.es >= 4) {
+    PNode& vals = nodes[(size_t)nn.child[nn.enc == ET_NULLABLE ? 0 : 1]];
+    if (vals.enc == ET_DICTIONARY && vals.rows > 0) vals.fused_gather = true;
+  }
   // children first
   for (int s = 0; s < 3; ++s)
     if (nn.child[s] >= 0) place(nn.child[s], false, nullptr);
@@ -636,7 +648,6 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
     }
     case ET_DICTIONARY: {
       NodeDesc d{};
-      d.self = mat_ref(es);
       d.c0 = C(1).ref;  // indices
       d.c1 = C(0).ref;  // alphabet
       {
@@ -656,6 +667,13 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
           lvl = std::max(lvl, C(0).ready + 1);
         }
       }
+      if (nn.fused_gather) {
+        nn.ref = d.c0; nn.ref.rows = rows;
+        nn.alpha_ref = d.c1; nn.alpha_ref.rows = C(0).rows;
+        nn.ready = lvl;
+        break;
+      }
+      d.self = mat_ref(es);
       d.rows = rows;
       const uint32_t dn = add_dnode(d);
       add_step(lvl, K_DICT_GATHER, es, dn, div_up32(rows, tile_rows));
@@ -670,6 +688,11 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       d.sel = nullable ? C(1).ref : C(0).ref;
       d.sel.rows = rows;
       d.c1 = nullable ? C(0).ref : C(1).ref;
+      if (const PNode& vals = nullable ? C(0) : C(1); vals.fused_gather) {
+        d.c0 = vals.alpha_ref;
+        d.c1.rows = vals.rows;
+        d.flags |= NF_DICT_VALUES;
+      }
       if (!nullable) {
         d.flags |= NF_INVERT_SEL;
         if (nn.is_string) {
