@@ -135,6 +135,8 @@ struct KArgs {
   uint8_t* work;
   const NodeDesc* nodes;   // in work
   const TileRef* tiles;    // in work, already offset to this launch's first tile
+  const uint32_t* tile_aux;  // per tile, parallel to `tiles`: for the rank-scatter tiles the slot of
+                             // their partial in `parts`, known without reading the node (0 otherwise)
   uint32_t* parts;         // tile partials (work)
   uint32_t* totals;        // per-node totals (work)
   uint32_t* status;        // status word (work)

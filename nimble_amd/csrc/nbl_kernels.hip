@@ -257,6 +257,42 @@ __device__ __forceinline__ uint8_t* self_ptr(const NodeDesc& nd, const KArgs& a)
 //
 // stage_tile: copies [p - mis, p + nbytes + 4) to `stage` (mis = p & 15) and
 // returns mis; the caller synchronises.  ROUNDS * 4096 bytes must cover it.
+// stage_load / stage_store: the same copy in two halves, so that independent
+// work (a scan with its barriers) runs while the loads are in flight.
+template <int ROUNDS>
+struct StageRegs {
+  u32x4 g[ROUNDS];
+  uint32_t nvec;
+};
+template <int ROUNDS>
+__device__ __forceinline__ uint32_t stage_load(const uint8_t* p, uint32_t nbytes, StageRegs<ROUNDS>& regs) {
+  const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 15u);
+  const u32x4* asrc = reinterpret_cast<const u32x4*>(p - mis);
+  const uint32_t nvec = (mis + nbytes + 4u + 15u) >> 4;
+  regs.nvec = nvec;
+  if (nvec <= kBlock) {
+    regs.g[0] = ld16_stream(asrc + (threadIdx.x < nvec ? threadIdx.x : nvec - 1));
+    return mis;
+  }
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const uint32_t i = r * kBlock + threadIdx.x;
+    regs.g[r] = ld16_stream(asrc + (i < nvec ? i : nvec - 1));
+  }
+  return mis;
+}
+template <int ROUNDS>
+__device__ __forceinline__ void stage_store(const StageRegs<ROUNDS>& regs, u32x4* stage) {
+  if (regs.nvec <= kBlock) {
+    if (threadIdx.x < regs.nvec) stage[threadIdx.x] = regs.g[0];
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < ROUNDS; ++r) {
+    const uint32_t i = r * kBlock + threadIdx.x;
+    if (i < regs.nvec) stage[i] = regs.g[r];
+  }
+}
 template <int ROUNDS>
 __device__ __forceinline__ uint32_t stage_tile(const uint8_t* p, uint32_t nbytes, u32x4* stage) {
   const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 15u);
@@ -404,6 +440,23 @@ struct Reader {
       const uint32_t mis = stage_tile<5>(p + (bit >> 3), (sh + n * bits_per_elem() + 7u) >> 3, reinterpret_cast<u32x4*>(lds));
       return Staged{*this, reinterpret_cast<const uint32_t*>(lds), mis * 8u + sh};
     }
+  }
+  // stage() in two halves: stage_begin issues the loads into registers,
+  // stage_end writes them to LDS (the caller synchronises after it)
+  __device__ __forceinline__ uint32_t stage_begin(uint64_t first, uint32_t n, StageRegs<5>& regs) const {
+    if constexpr (RK == RK_CONST) {
+      regs.nvec = 0;
+      return 0u;
+    } else {
+      const uint64_t bit = first * bits_per_elem();
+      const uint32_t sh = (uint32_t)bit & 7u;
+      const uint32_t mis = stage_load<5>(p + (bit >> 3), (sh + n * bits_per_elem() + 7u) >> 3, regs);
+      return mis * 8u + sh;
+    }
+  }
+  __device__ __forceinline__ Staged stage_end(const StageRegs<5>& regs, uint32_t bit0, uint8_t* lds) const {
+    if constexpr (RK != RK_CONST) stage_store<5>(regs, reinterpret_cast<u32x4*>(lds));
+    return Staged{*this, reinterpret_cast<const uint32_t*>(lds), bit0};
   }
   __device__ __forceinline__ View view(uint64_t first) const {
     if constexpr (RK == RK_PTR || RK == RK_CONST) {
@@ -741,7 +794,10 @@ __device__ __forceinline__ void body_scan_tiles(const KArgs& a, const NodeDesc& 
     if (i < n) p[i] = carry + ex;
     carry += total;
   }
-  if (threadIdx.x == 0) a.totals[nd.total_idx] = carry;
+  if (threadIdx.x == 0) {
+    a.totals[nd.total_idx] = carry;
+    p[n] = carry;  // so that tile t's share is p[t + 1] - p[t] for every t
+  }
 }
 
 // first_run[] of an RLE node sits behind its run-end array (R entries, 16-byte rounded)
@@ -1054,22 +1110,44 @@ __device__ __forceinline__ void body_sparse_bits(const KArgs& a, const NodeDesc&
 }
 
 // ---------------------------------------------------------- K_SELECT_SCATTER
+// In-tile exclusive scan of the popcounts of the W bitmap words of a tile
+// (thread i < W holds word i); leaves words and prefixes in LDS.  Up to 64
+// words fit one wave, which then needs no barrier of its own; the caller
+// synchronises before reading s_bits / s_pref.
+template <uint32_t W>
+__device__ __forceinline__ void tile_rank_scan(uint64_t word, uint64_t* s_bits, uint32_t* s_pref, uint32_t* tmp) {
+  if constexpr (W <= 64) {
+    if (threadIdx.x < 64) {
+      const uint32_t c = (uint32_t)__popcll(word);
+      const uint32_t incl = wave_incl_scan(c);
+      if (threadIdx.x < W) { s_bits[threadIdx.x] = word; s_pref[threadIdx.x] = incl - c; }
+    }
+  } else {
+    uint32_t total;
+    const uint32_t ex = block_excl_scan((uint32_t)__popcll(word), tmp, total);
+    if (threadIdx.x < W) { s_bits[threadIdx.x] = word; s_pref[threadIdx.x] = ex; }
+  }
+}
+
 // NullableEncoding::materialize (encodings/NullableEncoding.h:207-236): row i
 // takes values[rank(i)] when its bit is set, physicalType() otherwise; and
 // MainlyConstantEncoding::materialize (encodings/MainlyConstantEncoding.h:208-253):
 // the common value where isCommon is set, otherValues[rank0(i)] elsewhere.
 //
-// Selected rows take consecutive ranks, so the per-lane loads below are lane
-// monotone (coalesced).  They are issued unconditionally at a clamped rank --
-// a lane whose bit is clear loads its successor's value and drops it -- which
-// keeps every load of the tile in flight at once.
+// The selected rows of a tile take the consecutive ranks [parts[t], parts[t+1]),
+// so the tile's values are one contiguous range, staged in LDS while the
+// bitmap words are scanned.  `pslot` = the slot of the tile's partial in
+// `parts`, handed over by the tile table so that this load does not wait for
+// the node descriptor.
 template <int ES>
-__device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
+__device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem, uint32_t pslot) {
   using T = typename ElemT<ES>::type;
   constexpr uint32_t V = 16 / ES;
   constexpr uint32_t TE = select_tile_rows(ES);
   constexpr uint32_t W = TE / 64;
   static_assert(TE * ES == kTileBytes && W <= kBlock, "tile geometry");
+  const uint32_t base = a.parts[pslot];
+  const uint32_t next = a.parts[pslot + 1];  // the node's total sits behind its last partial
   uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem + kStageBytes);         // W <= 256 words
   uint32_t* s_pref = reinterpret_cast<uint32_t*>(smem + kStageBytes + 2048);  // W words
   uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + kStageBytes + 3072);
@@ -1084,8 +1162,6 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
   // from the scanned partials, so the values can be fetched without waiting for
   // the bitmap.  Counts that disagree with the values child (corrupt input) are
   // clamped, never followed.
-  const uint32_t base = a.parts[nd.part_base + tile];
-  const uint32_t next = tile + 1 < nd.n_parts ? a.parts[nd.part_base + tile + 1] : a.totals[nd.total_idx];
   const uint32_t count = next - base < TE ? next - base : TE;
   const uint32_t avail = base < nvals ? nvals - base : 0u;
   const uint32_t n = count < avail ? count : avail;
@@ -1114,16 +1190,15 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
     // The values child is a Dictionary whose gather is done here: c1 = its uint32
     // indices (staged like any values), c0 = its alphabet as a plain element
     // array.  The gathered rows never exist as an intermediate column.
-    const uint32_t A = nd.c0.rows;
     const Reader<RK_PTR, ES> alpha(nd.c0, a);
-    bool bad = A == 0;
-    const uint32_t amax = A ? A - 1 : 0;
+    bool bad = false;
+    const uint32_t amax = nd.c0.rows - 1;  // the planner fuses non-empty alphabets only
     with_reader<4>(nd.c1, a, [&](auto rd) {
-      const auto idxs = rd.stage(base, n, smem);
+      StageRegs<5> regs;
+      const uint32_t bit0 = rd.stage_begin(base, n, regs);
       write_nulls();
-      uint32_t total;
-      const uint32_t ex = block_excl_scan((uint32_t)__popcll(word), tmp, total);
-      if (threadIdx.x < W) { s_bits[threadIdx.x] = word; s_pref[threadIdx.x] = ex; }
+      tile_rank_scan<W>(word, s_bits, s_pref, tmp);
+      const auto idxs = rd.stage_end(regs, bit0, smem);
       __syncthreads();
       constexpr uint32_t IB = ES == 8 ? 4 : 2;  // rounds whose gathers are in flight together (8 rows)
 #pragma unroll
@@ -1150,7 +1225,7 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
 #pragma unroll
         for (uint32_t u = 0; u < IB; ++u)
 #pragma unroll
-          for (uint32_t j = 0; j < V; ++j) x[u][j] = A ? alpha.get(ix[u][j]) : fill;
+          for (uint32_t j = 0; j < V; ++j) x[u][j] = alpha.get(ix[u][j]);
 #pragma unroll
         for (uint32_t u = 0; u < IB; ++u) {
           const uint32_t q0 = ((ib + u) * kBlock + threadIdx.x) * V;
@@ -1170,11 +1245,11 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
   // (each byte fetched once) while the bitmap words are still in flight; every
   // row then unpacks its value -- or takes the fill -- from LDS at its rank.
   with_reader<ES>(nd.c1, a, [&](auto rd) {
-    const auto vals = rd.stage(base, n, smem);
+    StageRegs<5> regs;
+    const uint32_t bit0 = rd.stage_begin(base, n, regs);
     write_nulls();
-    uint32_t total;
-    const uint32_t ex = block_excl_scan((uint32_t)__popcll(word), tmp, total);
-    if (threadIdx.x < W) { s_bits[threadIdx.x] = word; s_pref[threadIdx.x] = ex; }
+    tile_rank_scan<W>(word, s_bits, s_pref, tmp);
+    const auto vals = rd.stage_end(regs, bit0, smem);
     __syncthreads();
 #pragma unroll
     for (uint32_t it = 0; it < 4; ++it) {
@@ -1621,7 +1696,7 @@ __device__ __forceinline__ void body_frame_unpack(const KArgs& a, const NodeDesc
 // ================================================================ dispatch
 // run_op<OP>: the body of operation OP = make_op(kernel, element size).
 template <uint32_t OP>
-__device__ __forceinline__ void run_op(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
+__device__ __forceinline__ void run_op(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem, uint32_t aux) {
   constexpr uint32_t K = OP / 4;
   constexpr int ES = 1 << (OP % 4);
   if constexpr (K == K_MATERIALIZE) body_materialize<ES>(a, nd, tile, smem);
@@ -1636,7 +1711,7 @@ __device__ __forceinline__ void run_op(const KArgs& a, const NodeDesc& nd, uint3
   else if constexpr (K == K_RLE_EXPAND) body_rle_expand<ES>(a, nd, tile, smem);
   else if constexpr (K == K_RLE_EXPAND_BOOL) body_rle_expand_bool(a, nd, tile, smem);
   else if constexpr (K == K_SPARSE_BITS) body_sparse_bits(a, nd, tile, smem);
-  else if constexpr (K == K_SELECT_SCATTER) body_select_scatter<ES>(a, nd, tile, smem);
+  else if constexpr (K == K_SELECT_SCATTER) body_select_scatter<ES>(a, nd, tile, smem, aux);
   else if constexpr (K == K_SELECT_BITS) body_select_bits(a, nd, tile, smem);
   else if constexpr (K == K_DICT_GATHER) body_dict_gather<ES>(a, nd, tile, smem);
   else if constexpr (K == K_VARINT_DECODE) body_varint_decode<(ES == 4 ? 4 : 8)>(a, nd, tile, smem);
@@ -1650,7 +1725,8 @@ template <uint32_t OP>
 __device__ __forceinline__ void single_op_kernel(const KArgs& a) {
   __shared__ __align__(16) uint8_t smem[kSmemBytes];
   const TileRef tr = a.tiles[blockIdx.x];
-  run_op<OP>(a, a.nodes[tr.node], tr.tile & kTileMask, smem);
+  const uint32_t aux = a.tile_aux[blockIdx.x];
+  run_op<OP>(a, a.nodes[tr.node], tr.tile & kTileMask, smem, aux);
 }
 #define NBL_KERNEL_ES(name, KID) \
   template <int ES> __global__ __launch_bounds__(256) void name(KArgs a) { single_op_kernel<make_op(KID, ES)>(a); }
@@ -1687,9 +1763,10 @@ template <bool LAST>
 __global__ __launch_bounds__(256, 8) void k_level(KArgs a) {
   __shared__ __align__(16) uint8_t smem[kSmemBytes];
   const TileRef tr = a.tiles[blockIdx.x];
+  const uint32_t aux = a.tile_aux[blockIdx.x];
   const NodeDesc& nd = a.nodes[tr.node];
   const uint32_t tile = tr.tile & kTileMask;
-#define NBL_OP(KID, ES) case make_op(KID, ES): run_op<make_op(KID, ES)>(a, nd, tile, smem); break;
+#define NBL_OP(KID, ES) case make_op(KID, ES): run_op<make_op(KID, ES)>(a, nd, tile, smem, aux); break;
 #define NBL_OP_ALL_ES(KID) NBL_OP(KID, 1) NBL_OP(KID, 2) NBL_OP(KID, 4) NBL_OP(KID, 8)
   switch (tr.tile >> kOpShift) {
     NBL_OP_ALL_ES(K_MATERIALIZE)

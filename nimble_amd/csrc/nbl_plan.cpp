@@ -138,11 +138,12 @@ struct nbl_plan {
   std::vector<Step> steps;
   std::vector<Launch> launches;
   std::vector<TileRef> tiles;
+  std::vector<uint32_t> tile_aux;         // parallel to tiles (KArgs::tile_aux)
   bool keep_dictionary = false;  // also emit alphabet + indices of dictionary chunks
   bool fused = true;          // one launch per cascade level (default) or one per (level, kernel, element size)
   int cur_chunk = -1;         // chunk being planned
   std::vector<uint8_t> blob;  // NodeDesc[] | TileRef[] image uploaded to work
-  uint64_t tiles_off = 0;
+  uint64_t tiles_off = 0, aux_off = 0;
   uint64_t ctrl_off = 0, ctrl_bytes = 0;   // status word + per-node totals (zeroed per decode)
   uint64_t parts_off = 0;
   uint32_t n_parts = 0, n_totals = 0;
@@ -174,7 +175,7 @@ struct nbl_plan {
     steps.push_back(Step{level, kernel, es, dnode, n_tiles, per_node, -1, cur_chunk, 0, 0});
   }
   void alloc_scan(NodeDesc& d, uint32_t n_tiles) {
-    d.part_base = n_parts; d.n_parts = n_tiles; n_parts += n_tiles;
+    d.part_base = n_parts; d.n_parts = n_tiles; n_parts += n_tiles + 1;  // + the node's total behind its last partial
     d.total_idx = n_totals; n_totals += 2;
   }
   uint64_t string_copy(int level, uint64_t arena_off, uint64_t bytes);
@@ -524,7 +525,7 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
   // and re-reading every non-null row.
   if ((nn.enc == ET_NULLABLE || nn.enc == ET_MAINLYCONSTANT) && !nn.is_bool && nn.es >= 4) {
     PNode& vals = nodes[(size_t)nn.child[nn.enc == ET_NULLABLE ? 0 : 1]];
-    if (vals.enc == ET_DICTIONARY && vals.rows > 0) vals.fused_gather = true;
+    if (vals.enc == ET_DICTIONARY && vals.rows > 0 && nodes[(size_t)vals.child[0]].rows > 0) vals.fused_gather = true;
   }
   // children first
   for (int s = 0; s < 3; ++s)
@@ -915,6 +916,7 @@ void nbl_plan::finish() {
     size_t n_tiles_total = 0;
     for (const Step& st : steps) n_tiles_total += st.n_tiles;
     tiles.reserve(n_tiles_total);
+    tile_aux.reserve(n_tiles_total);
   }
   for (size_t i = 0; i < steps.size();) {
     size_t j = i;
@@ -923,7 +925,11 @@ void nbl_plan::finish() {
     while (j < steps.size() && steps[j].level == steps[i].level &&
            (fuse ? kernel_is_fusable(steps[j].kernel) : (steps[j].kernel == steps[i].kernel && steps[j].es == steps[i].es))) {
       const uint32_t op = op_of(steps[j].kernel, steps[j].es) << kOpShift;
-      for (uint32_t t = 0; t < steps[j].n_tiles; ++t) tiles.push_back(TileRef{steps[j].dnode, op | (steps[j].tile_begin + t)});
+      const uint32_t aux_base = steps[j].kernel == K_SELECT_SCATTER ? dnodes[steps[j].dnode].part_base : 0u;
+      for (uint32_t t = 0; t < steps[j].n_tiles; ++t) {
+        tiles.push_back(TileRef{steps[j].dnode, op | (steps[j].tile_begin + t)});
+        tile_aux.push_back(steps[j].kernel == K_SELECT_SCATTER ? aux_base + steps[j].tile_begin + t : 0u);
+      }
       L.alg_bytes += steps[j].alg;
       ++j;
     }
@@ -939,11 +945,13 @@ void nbl_plan::finish() {
     launches.push_back(L);
     i = j;
   }
-  // work = [NodeDesc[] | TileRef[]] [ctrl] [parts] [intermediates...]
+  // work = [NodeDesc[] | TileRef[] | tile_aux[]] [ctrl] [parts] [intermediates...]
   const uint64_t nd_bytes = align_up(dnodes.size() * sizeof(NodeDesc), kAlign);
   const uint64_t tl_bytes = align_up(tiles.size() * sizeof(TileRef), kAlign);
+  const uint64_t ax_bytes = align_up(tile_aux.size() * sizeof(uint32_t), kAlign);
   tiles_off = nd_bytes;
-  desc_bytes = nd_bytes + tl_bytes;
+  aux_off = nd_bytes + tl_bytes;
+  desc_bytes = nd_bytes + tl_bytes + ax_bytes;
   ctrl_off = desc_bytes;
   ctrl_bytes = align_up(4 + (uint64_t)n_totals * 4, kAlign);
   parts_off = ctrl_off + ctrl_bytes;
@@ -961,6 +969,7 @@ void nbl_plan::finish() {
   blob.assign(desc_bytes, 0);
   if (!dnodes.empty()) memcpy(blob.data(), dnodes.data(), dnodes.size() * sizeof(NodeDesc));
   if (!tiles.empty()) memcpy(blob.data() + tiles_off, tiles.data(), tiles.size() * sizeof(TileRef));
+  if (!tile_aux.empty()) memcpy(blob.data() + aux_off, tile_aux.data(), tile_aux.size() * sizeof(uint32_t));
 }
 
 // =============================== C ABI =====================================
@@ -1187,10 +1196,12 @@ static nbl_status decode_impl(const nbl_plan* p, nbl_profile* prof, uint32_t ste
   a.totals = a.status + 1;
   a.parts = reinterpret_cast<uint32_t*>(work + p->parts_off);
   const TileRef* tiles = reinterpret_cast<const TileRef*>(work + p->tiles_off);
+  const uint32_t* tile_aux = reinterpret_cast<const uint32_t*>(work + p->aux_off);
   const size_t nl = p->launches.size();
   for (size_t li = 0; li < nl; ++li) {
     const Launch& L = p->launches[li];
     a.tiles = tiles + L.tile_begin;
+    a.tile_aux = tile_aux + L.tile_begin;
     a.n_tiles = L.n_tiles;
     if (prof && (li == 0 || prof->group_of[li] != prof->group_of[li - 1]))
       (void)hipEventRecord(prof->events[(size_t)step * (prof->n_groups + 1) + prof->group_of[li]], static_cast<hipStream_t>(stream));
