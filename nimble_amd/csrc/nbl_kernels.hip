@@ -405,10 +405,10 @@ struct Reader {
       }
     }
   };
-  // Elements [first, first + n) copied as raw bytes into LDS with aligned,
-  // non-temporal 16-byte loads (stage_tile); at(rel) then unpacks element
+  // Elements [first, first + n) copied as raw bytes into LDS with aligned
+  // 16-byte loads (stage_begin / stage_end); at(rel) then unpacks element
   // first + rel from LDS.  The range must fit kTileBytes (see fits()); the
-  // caller synchronises between stage() and at().
+  // caller synchronises between stage_end() and at().
   struct Staged {
     const Reader& r;
     const uint32_t* s32;
@@ -434,17 +434,7 @@ struct Reader {
   };
   __device__ __forceinline__ uint32_t bits_per_elem() const { return RK == RK_PTR ? 8u * CES : RK == RK_CONST ? 0u : w; }
   __device__ __forceinline__ bool fits(uint32_t n) const { return (uint64_t)n * bits_per_elem() <= 8ull * kTileBytes; }
-  __device__ __forceinline__ Staged stage(uint64_t first, uint32_t n, uint8_t* lds) const {
-    if constexpr (RK == RK_CONST) {
-      return Staged{*this, reinterpret_cast<const uint32_t*>(lds), 0u};
-    } else {
-      const uint64_t bit = first * bits_per_elem();
-      const uint32_t sh = (uint32_t)bit & 7u;
-      const uint32_t mis = stage_tile<5>(p + (bit >> 3), (sh + n * bits_per_elem() + 7u) >> 3, reinterpret_cast<u32x4*>(lds));
-      return Staged{*this, reinterpret_cast<const uint32_t*>(lds), mis * 8u + sh};
-    }
-  }
-  // stage() in two halves: stage_begin issues the loads into registers,
+  // Staging in two halves: stage_begin issues the loads into registers,
   // stage_end writes them to LDS (the caller synchronises after it)
   __device__ __forceinline__ uint32_t stage_begin(uint64_t first, uint32_t n, StageRegs<5>& regs) const {
     if constexpr (RK == RK_CONST) {
