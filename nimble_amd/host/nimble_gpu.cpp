@@ -549,6 +549,20 @@ std::unique_ptr<Encoding> GpuEncodingFactory::create(std::string_view data, Stri
   }
 }
 
+std::string toString(EncodingType t) {
+  static const char* const names[] = {"Trivial", "RLE", "Dictionary", "FixedBitWidth", "Sentinel", "Nullable", "SparseBool", "Varint",
+                                      "Delta", "Constant", "MainlyConstant", "Prefix", "ALP", "PFOR", "SimdForBitpack", "BlockBitPacking",
+                                      "SubIntSplit", "FrequencyPartition", "FOR", "Fsst", "Huffman", "DeltaBlock", "SharedDictionary"};
+  const unsigned v = static_cast<uint8_t>(t);
+  return v < sizeof names / sizeof names[0] ? names[v] : "Unknown encoding type: " + std::to_string(v);
+}
+std::string toString(DataType t) {
+  static const char* const names[] = {nullptr, "Int8", "Uint8", "Int16", "Uint16", "Int32", "Uint32", "Int64", "Uint64", "Float", "Double",
+                                      "Bool", "String"};
+  const unsigned v = static_cast<uint8_t>(t);
+  return v >= 1 && v < sizeof names / sizeof names[0] ? names[v] : "Unknown data type: " + std::to_string(v);
+}
+
 bool supportsEncodingView(EncodingType t) {
   switch (t) {
     case EncodingType::Constant: case EncodingType::Trivial: case EncodingType::MainlyConstant:

@@ -62,6 +62,10 @@ enum class DataType : uint8_t {
   Float = 9, Double = 10, Bool = 11, String = 12
 };
 
+// toString(EncodingType) / toString(DataType), dwio/nimble/common/Types.cpp:25-120
+std::string toString(EncodingType encodingType);
+std::string toString(DataType dataType);
+
 // Encoding::Options fields that matter on the decode side (Encoding.h:115-175).
 struct Options {
   bool useVarintRowCount = false;
@@ -91,6 +95,11 @@ class Encoding {
   virtual uint32_t materializeNullable(uint32_t rowCount, void* buffer, std::function<void*()> getOutputNulls,
                                        const Bitmap* scatterOutputBitmap = nullptr, uint32_t offset = 0) = 0;
   virtual void materializeBoolsAsBits(uint32_t rowCount, uint64_t* buffer, int begin) = 0;
+  // "<indent>Encoding<DataType> rowCount=N" (Encoding::debugString, Encoding.cpp:45-52)
+  virtual std::string debugString(int offset = 0) const {
+    return std::string((size_t)(offset > 0 ? offset : 0), ' ') + toString(encodingType()) + "<" + toString(dataType()) + "> rowCount=" +
+           std::to_string(rowCount());
+  }
   // Dictionary API (Encoding.h:277-311).  True for a Dictionary chunk and for a
   // Nullable chunk over one (NullableEncoding.h:107-122) when the factory was
   // asked to keep dictionaries; everything else answers false, which sends a

@@ -88,6 +88,11 @@ uint32_t nblh_null_count(void* e) { return E(e).nullCount(); }
 int nblh_is_nullable(void* e) { return E(e).isNullable(); }
 int nblh_data_type(void* e) { return (int)E(e).dataType(); }
 int nblh_encoding_type(void* e) { return (int)E(e).encodingType(); }
+// debugString into buf (truncated to cap - 1 characters)
+void nblh_debug_string(void* e, int offset, char* buf, uint32_t cap) {
+  const std::string s = E(e).debugString(offset);
+  if (cap) { strncpy(buf, s.c_str(), cap - 1); buf[cap - 1] = 0; }
+}
 int nblh_reset(void* e) { return guard([&] { E(e).reset(); }); }
 int nblh_skip(void* e, uint32_t n) { return guard([&] { E(e).skip(n); }); }
 int nblh_materialize(void* e, uint32_t n, void* buffer) { return guard([&] { E(e).materialize(n, buffer); }); }

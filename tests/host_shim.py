@@ -42,6 +42,7 @@ def lib():
         for f in ("nblh_is_nullable", "nblh_data_type", "nblh_encoding_type", "nblh_reset"):
             getattr(L, f).restype = i32
             getattr(L, f).argtypes = [vp]
+        L.nblh_debug_string.argtypes = [vp, i32, C.c_char_p, u32]
         L.nblh_skip.argtypes = [vp, u32]
         L.nblh_materialize.argtypes = [vp, u32, vp]
         L.nblh_materialize_bools_as_bits.argtypes = [vp, u32, vp, i32]
@@ -147,6 +148,11 @@ class HostEncoding:
         if getattr(self, "_h", None):
             lib().nblh_encoding_free(self._h)
             self._h = None
+
+    def debug_string(self, offset=0):
+        buf = C.create_string_buffer(256)
+        lib().nblh_debug_string(self._h, offset, buf, 256)
+        return buf.value.decode()
 
     def reset(self):
         _chk(lib().nblh_reset(self._h))

@@ -102,6 +102,9 @@ def test_error_convention(factory):
     e = factory.create(ok)
     with pytest.raises(host_shim.HostError, match="past the end"):
         e.materialize(5)
+    # Encoding::debugString (encodings/common/Encoding.cpp:45-52)
+    assert e.debug_string() == "Trivial<Int32> rowCount=4"
+    assert factory.create(E.encode(E.FOR(), np.arange(9, dtype=np.uint64), W.UINT64)).debug_string(2) == "  FOR<Uint64> rowCount=9"
 
 
 def _stream(rng, dtype, with_nulls, max_chunks=10, max_rows=10):
