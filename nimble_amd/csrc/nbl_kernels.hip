@@ -909,11 +909,19 @@ __device__ __forceinline__ void body_rle_expand(const KArgs& a, const NodeDesc& 
     return;
   }
   const bool zero_runs = a.totals[nd.total_idx + 1] != 0;
+  uint32_t k0, k1;
+  uint32_t e_first = 0;  // run end this thread marks first (loaded before the barrier below)
   if (zero_runs) {
     find_run_range(ends, R, p0, p1, s_k);
-  } else if (threadIdx.x == 0) {
+    if (threadIdx.x < W) s_bits[threadIdx.x] = 0;
+    __syncthreads();
+    k0 = s_k[0];
+    k1 = s_k[1] < s_k[0] ? s_k[0] : s_k[1];
+  } else {
     // runs of the tile: from the run holding its first row to the run holding the
-    // next tile's first row (clamped: these come from payload data)
+    // next tile's first row (clamped: these come from payload data).  Every
+    // thread reads the two entries itself (one address: a scalar load), so the
+    // first run ends are in flight before the barrier.
     const uint32_t* first_run = rle_first_run(a, nd);
     const uint32_t f0 = first_run[tile];
     const uint32_t f1 = p0 + TE < rows ? first_run[tile + 1] : R - 1;
@@ -921,17 +929,18 @@ __device__ __forceinline__ void body_rle_expand(const KArgs& a, const NodeDesc& 
     uint32_t c1 = f1 < R ? f1 : R - 1;
     if (c1 < c0) c1 = c0;
     if (c1 - c0 >= TE) c1 = c0 + TE - 1;  // a tile of TE rows meets at most TE non-empty runs
-    s_k[0] = c0; s_k[1] = c1;
+    k0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);
+    k1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c1);
+    if (k0 + threadIdx.x < k1) e_first = ends[k0 + threadIdx.x];
+    if (threadIdx.x < W) s_bits[threadIdx.x] = 0;
+    __syncthreads();
   }
-  if (threadIdx.x < W) s_bits[threadIdx.x] = 0;
-  __syncthreads();
-  const uint32_t k0 = s_k[0], k1 = s_k[1] < s_k[0] ? s_k[0] : s_k[1];
   const uint32_t nruns = k1 - k0 + 1;
   const bool slow = zero_runs || nruns > TE;
   if (!slow) {
     uint32_t* bits32 = reinterpret_cast<uint32_t*>(s_bits);
     for (uint32_t j = k0 + threadIdx.x; j < k1; j += kBlock) {
-      const uint64_t e = ends[j];
+      const uint64_t e = j < k0 + kBlock ? e_first : ends[j];
       if (e > p0 && e < p1) {
         const uint32_t q = (uint32_t)(e - p0);
         atomicOr(&bits32[q >> 5], 1u << (q & 31));
@@ -943,10 +952,18 @@ __device__ __forceinline__ void body_rle_expand(const KArgs& a, const NodeDesc& 
       for (uint32_t j = threadIdx.x; j < nruns; j += kBlock) s_vals[j] = src.at(j);
     });
     __syncthreads();
-    uint32_t pc = threadIdx.x < W ? (uint32_t)__popcll(s_bits[threadIdx.x]) : 0;
-    uint32_t total;
-    const uint32_t ex = block_excl_scan(pc, tmp, total);
-    if (threadIdx.x < W) s_pref[threadIdx.x] = ex;
+    if constexpr (W <= 64) {  // one wave holds every boundary word of the tile: scan without further barriers
+      if (threadIdx.x < 64) {
+        const uint32_t pc = threadIdx.x < W ? (uint32_t)__popcll(s_bits[threadIdx.x]) : 0u;
+        const uint32_t incl = wave_incl_scan(pc);
+        if (threadIdx.x < W) s_pref[threadIdx.x] = incl - pc;
+      }
+    } else {
+      uint32_t pc = threadIdx.x < W ? (uint32_t)__popcll(s_bits[threadIdx.x]) : 0;
+      uint32_t total;
+      const uint32_t ex = block_excl_scan(pc, tmp, total);
+      if (threadIdx.x < W) s_pref[threadIdx.x] = ex;
+    }
     __syncthreads();
 #pragma unroll
     for (uint32_t it = 0; it < 4; ++it) {
