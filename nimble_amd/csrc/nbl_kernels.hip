@@ -1634,8 +1634,17 @@ __device__ __forceinline__ void body_copy_bytes(const KArgs& a, const NodeDesc& 
 // baseline c0[s], bit width c1[s] and start sel[s] in the packed payload (byte
 // offset for blocks, bit offset for frames).  Inside a segment the values are a
 // plain LSB-first bit stream.  The three per-segment arrays are element arrays
-// in work.  Every lane decodes 16 bytes of consecutive rows per round and keeps
-// the segment's parameters while the rows stay inside it.
+// in work.
+//
+// A tile first reads the parameters of the segments it touches (one thread per
+// segment) into LDS and validates their bit ranges, then stages the payload
+// bytes between the lowest and the highest bit its rows need with aligned
+// 16-byte loads; every lane then unpacks 16 bytes of consecutive rows per round
+// from one LDS window, as the FixedBitWidth kernel does.  Vectors that straddle
+// two segments, segments whose range or width is not acceptable, and tiles
+// whose segments are too many or too scattered for LDS are decoded row by row
+// from global memory (frame_row), which is also where inconsistencies are
+// reported.
 __device__ __forceinline__ uint64_t bits_get(const uint8_t* payload, uint64_t bit, uint32_t w) {
   const uint8_t* p = payload + (bit >> 3);
   const uint32_t sh = (uint32_t)bit & 7u;
@@ -1643,62 +1652,167 @@ __device__ __forceinline__ uint64_t bits_get(const uint8_t* payload, uint64_t bi
   if (w + sh > 64) v |= (uint64_t)p[8] << (64 - sh);
   return v & wmask(w);
 }
+struct FrameGeom {
+  uint32_t seg_size, seg_first, shift;
+  bool pow2;
+  __device__ __forceinline__ uint32_t seg_of(uint32_t row) const {
+    if (row < seg_first) return 0u;
+    const uint32_t d = row - seg_first;
+    return 1u + (pow2 ? d >> shift : d / seg_size);
+  }
+  __device__ __forceinline__ uint32_t row0(uint32_t s) const { return s ? seg_first + (s - 1u) * seg_size : 0u; }
+  __device__ __forceinline__ uint32_t len(uint32_t s) const { return s ? seg_size : seg_first; }
+};
 template <int ES>
-__device__ __forceinline__ void body_frame_unpack(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t*) {
+__device__ __forceinline__ typename ElemT<ES>::type frame_row(const KArgs& a, const NodeDesc& nd, const FrameGeom& g, uint32_t row,
+                                                              uint32_t& bad) {
+  using T = typename ElemT<ES>::type;
+  const bool frames = (nd.flags & NF_FRAME_BITS) != 0;
+  const uint8_t* payload = a.arena + nd.aux_off;
+  const uint64_t payload_bits = nd.aux * 8;
+  const uint32_t s = g.seg_of(row);
+  const uint32_t r = row - g.row0(s);
+  const uint32_t w = (a.work + nd.c1.off)[s];
+  const T base = reinterpret_cast<const T*>(a.work + nd.c0.off)[s];
+  const uint8_t* offs = a.work + nd.sel.off;
+  const uint64_t bit0 = frames ? reinterpret_cast<const uint64_t*>(offs)[s] : (uint64_t)reinterpret_cast<const uint32_t*>(offs)[s] * 8u;
+  if (!frames && w == 255u) {  // block stored as raw values
+    const uint64_t byte = (bit0 >> 3) + (uint64_t)r * ES;
+    if ((byte + ES) * 8u <= payload_bits) return ld_elem<ES>(payload + byte);
+    bad = 1;
+    return 0;
+  }
+  if (w == 0) return base;
+  if (w > 64u || (!frames && w >= 8u * ES)) {
+    bad = 1;
+    return 0;
+  }
+  const uint64_t rel = (uint64_t)r * w;
+  if (bit0 <= payload_bits && rel <= payload_bits - bit0 && w <= payload_bits - bit0 - rel) return (T)(bits_get(payload, bit0 + rel, w) + base);
+  bad = 1;
+  return 0;
+}
+constexpr uint32_t kFrameMaxSegs = 160;  // segments of one tile whose parameters fit behind the staged bytes
+constexpr uint32_t kFrameSlowSeg = 0xFFu;
+static_assert(kStageBytes % 16 == 0 && kStageBytes + kFrameMaxSegs * 17 + 8 <= kSmemBytes, "segment tables fit behind the stage");
+template <int ES>
+__device__ __forceinline__ void body_frame_unpack(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
   using T = typename ElemT<ES>::type;
   constexpr uint32_t V = 16 / ES;
   constexpr uint32_t TE = kTileBytes / ES;
+  constexpr uint32_t WFULL = 8 * ES;
   const uint32_t rows = nd.rows;
   const uint32_t start = tile * TE;
-  T* dst = reinterpret_cast<T*>(self_ptr(nd, a));
-  const T* bases = reinterpret_cast<const T*>(a.work + nd.c0.off);
-  const uint8_t* widths = a.work + nd.c1.off;
-  const uint8_t* offs = a.work + nd.sel.off;
+  const uint32_t tile_rows = rows - start < TE ? rows - start : TE;
+  T* dst = reinterpret_cast<T*>(self_ptr(nd, a)) + start;
   const bool frames = (nd.flags & NF_FRAME_BITS) != 0;
-  const uint32_t seg_size = (uint32_t)nd.aux2, seg_first = (uint32_t)(nd.aux2 >> 32);
+  FrameGeom g;
+  g.seg_size = (uint32_t)nd.aux2;
+  g.seg_first = (uint32_t)(nd.aux2 >> 32);
+  g.pow2 = (g.seg_size & (g.seg_size - 1u)) == 0;
+  g.shift = (uint32_t)__builtin_ctz(g.seg_size);
   const uint8_t* payload = a.arena + nd.aux_off;
   const uint64_t payload_bits = nd.aux * 8;
+
+  u32x4* stage = reinterpret_cast<u32x4*>(smem);
+  uint64_t* s_base = reinterpret_cast<uint64_t*>(smem + kStageBytes);
+  uint64_t* s_bit = s_base + kFrameMaxSegs;
+  uint8_t* s_w = reinterpret_cast<uint8_t*>(s_bit + kFrameMaxSegs);
+  uint32_t* s_range = reinterpret_cast<uint32_t*>(s_w + kFrameMaxSegs);  // lowest / highest payload byte needed
+
+  const uint32_t s_lo = g.seg_of(start);
+  const uint32_t nseg = g.seg_of(start + tile_rows - 1u) - s_lo + 1u;
+  bool tile_fast = nseg <= kFrameMaxSegs;
+  if (threadIdx.x == 0) {
+    s_range[0] = ~0u;
+    s_range[1] = 0u;
+  }
+  __syncthreads();
+  if (tile_fast && threadIdx.x < nseg) {
+    const uint32_t s = s_lo + threadIdx.x;
+    const uint32_t w = (a.work + nd.c1.off)[s];
+    T base = reinterpret_cast<const T*>(a.work + nd.c0.off)[s];
+    const uint8_t* offs = a.work + nd.sel.off;
+    uint64_t off = frames ? reinterpret_cast<const uint64_t*>(offs)[s] : (uint64_t)reinterpret_cast<const uint32_t*>(offs)[s] * 8u;
+    const uint32_t seg_row0 = g.row0(s);
+    const uint32_t r_lo = start > seg_row0 ? start - seg_row0 : 0u;          // rows of the segment inside the tile
+    const uint32_t r_end = start + tile_rows - seg_row0;
+    const uint32_t r_hi = r_end < g.len(s) ? r_end : g.len(s);
+    const bool raw = !frames && w == 255u;
+    const uint32_t weff = raw ? WFULL : w;
+    uint32_t code = kFrameSlowSeg;
+    if (raw || (frames ? w <= WFULL : w < WFULL)) {
+      if (weff == 0) {
+        code = 0;
+      } else if (off <= payload_bits && (uint64_t)r_hi * weff <= payload_bits - off) {
+        code = weff;
+        atomicMin(&s_range[0], (uint32_t)((off + (uint64_t)r_lo * weff) >> 3));
+        atomicMax(&s_range[1], (uint32_t)((off + (uint64_t)r_hi * weff + 7u) >> 3));
+      }
+      if (raw) base = 0;
+    }
+    s_w[threadIdx.x] = (uint8_t)code;
+    s_base[threadIdx.x] = base;
+    s_bit[threadIdx.x] = off;
+  }
+  __syncthreads();
+  const uint32_t lo = s_range[0], hi = s_range[1];
+  uint32_t mis = 0;
+  if (tile_fast && lo < hi) {
+    if (hi - lo > kStageBytes - 19u) tile_fast = false;  // the needed bytes are spread too far for LDS
+    else mis = stage_tile<5>(payload + lo, hi - lo, stage);
+  }
+  __syncthreads();
+  const uint32_t* s32 = reinterpret_cast<const uint32_t*>(stage);
+
+  uint32_t slow_rounds = 0;
+#pragma unroll
+  for (uint32_t it = 0; it < 4; ++it) {
+    const uint32_t q = (it * kBlock + threadIdx.x) * V;
+    if (q >= tile_rows) continue;
+    bool done = false;
+    if (tile_fast) {
+      const uint32_t row = start + q;
+      const uint32_t s = g.seg_of(row);
+      const uint32_t r = row - g.row0(s);
+      const uint32_t here = tile_rows - q < V ? tile_rows - q : V;
+      const uint32_t code = s_w[s - s_lo];
+      if (g.len(s) - r >= here && code != kFrameSlowSeg) {
+        const T base = (T)s_base[s - s_lo];
+        Vec16<ES> x;
+        if (code == 0) {
+          unpack_window<ES>(0u, 0u, 0u, 0u, 0u, base, x);
+        } else {
+          const uint32_t lb = (uint32_t)(s_bit[s - s_lo] - (uint64_t)lo * 8u) + mis * 8u + r * code;
+          uint32_t n0, n1, n2, n3;
+          lds_window(s32, lb, n0, n1, n2, n3);
+          if (code == WFULL) {
+            x.q = make_u32x4(n0, n1, n2, n3);
+            vec_add_base<ES>(x, base);
+          } else {
+            unpack_window<ES>(n0, n1, n2, n3, code, base, x);
+          }
+        }
+        store_vec<ES>(dst, q, tile_rows, x);
+        done = true;
+      }
+    }
+    if (!done) slow_rounds |= 1u << it;
+  }
   uint32_t bad = 0;
 #pragma unroll 1
   for (uint32_t it = 0; it < 4; ++it) {
-    const uint32_t q0 = start + (it * kBlock + threadIdx.x) * V;
-    if (q0 >= rows) break;
+    if (!((slow_rounds >> it) & 1u)) continue;
+    const uint32_t q = (it * kBlock + threadIdx.x) * V;
     Vec16<ES> x;
     x.q = make_u32x4(0, 0, 0, 0);
-    uint32_t cur = ~0u, w = 0, seg_row0 = 0;
-    T base = 0;
-    uint64_t bit0 = 0;
 #pragma unroll
     for (uint32_t j = 0; j < V; ++j) {
-      const uint32_t row = q0 + j;
       T val = 0;
-      if (row < rows) {
-        const uint32_t s = row < seg_first ? 0u : 1u + (row - seg_first) / seg_size;
-        if (s != cur) {
-          cur = s;
-          w = widths[s];
-          base = bases[s];
-          seg_row0 = s ? seg_first + (s - 1u) * seg_size : 0u;
-          bit0 = frames ? reinterpret_cast<const uint64_t*>(offs)[s] : (uint64_t)reinterpret_cast<const uint32_t*>(offs)[s] * 8u;
-        }
-        const uint32_t r = row - seg_row0;
-        if (!frames && w == 255u) {  // block stored as raw values
-          const uint64_t byte = (bit0 >> 3) + (uint64_t)r * ES;
-          if ((byte + ES) * 8u <= payload_bits) val = ld_elem<ES>(payload + byte);
-          else bad = 1;
-        } else if (w == 0) {
-          val = base;
-        } else if (w > 64u || (!frames && w >= 8u * ES)) {
-          bad = 1;
-        } else {
-          const uint64_t bit = bit0 + (uint64_t)r * w;
-          if (bit <= payload_bits && w <= payload_bits - bit) val = (T)(bits_get(payload, bit, w) + base);
-          else bad = 1;
-        }
-      }
+      if (q + j < tile_rows) val = frame_row<ES>(a, nd, g, start + q + j, bad);
       vec_set<ES>(x, j, val);
     }
-    store_vec<ES>(dst, q0, rows, x);
+    store_vec<ES>(dst, q, tile_rows, x);
   }
   if (bad) atomicOr(a.status, ST_FRAME_RANGE);
 }

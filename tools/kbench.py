@@ -77,6 +77,14 @@ CASES = {
     "varint/i64": lambda: E.encode(E.Varint(), rng.integers(0, 1 << 20, N).astype(np.uint64), W.INT64),
     "varint/i32": lambda: E.encode(E.Varint(), rng.integers(0, 1 << 14, N).astype(np.uint32), W.INT32),
     "const/i64": lambda: E.encode(E.Constant(), np.full(N, 7, dtype=np.uint64), W.INT64),
+    "block/bbp/i64/narrow": lambda: E.encode(E.BlockBitPacking(), (rng.integers(0, 1 << 13, N) + (1 << 40)).astype(np.uint64), W.INT64),
+    "block/bbp/i32/narrow": lambda: E.encode(E.BlockBitPacking(), (rng.integers(0, 1 << 13, N) + (1 << 20)).astype(np.uint32), W.INT32),
+    "block/bbp/i64/raw": lambda: E.encode(E.BlockBitPacking(), rng.integers(0, 1 << 63, N, dtype=np.uint64) * np.uint64(2), W.INT64),
+    "block/for/i64/narrow": lambda: E.encode(E.FOR(), (rng.integers(0, 1 << 13, N) + (1 << 40)).astype(np.uint64), W.INT64),
+    "block/for/i32/narrow": lambda: E.encode(E.FOR(), (rng.integers(0, 1 << 13, N) + (1 << 20)).astype(np.uint32), W.INT32),
+    "fbw/i64/w13": lambda: E.encode(E.FixedBitWidth(bit_width=13), rng.integers(0, 1 << 13, N).astype(np.uint64), W.INT64),
+    "fbw/i32/w13": lambda: E.encode(E.FixedBitWidth(bit_width=13), rng.integers(0, 1 << 13, N).astype(np.uint32), W.INT32),
+    "fbw/i32/w16": lambda: E.encode(E.FixedBitWidth(bit_width=16), rng.integers(0, 1 << 16, N).astype(np.uint32), W.INT32),
     "string/trivial": lambda: E.encode(E.Trivial(lengths=E.FixedBitWidth()), WL.random_alphabet(rng, 400_000), W.STRING),
 }
 
