@@ -78,6 +78,57 @@ def test_block_encodings_nested(gpu, oracle):
     check_parity(oracle, encs)
 
 
+def test_tiles_with_many_segments(gpu, oracle):
+    """Segments far smaller than a 16 KiB tile of rows (hundreds per tile, more
+    than the kernel keeps parameters for) and just below that limit."""
+    rng = np.random.default_rng(160)
+    encs, labels = [], []
+    for dtype, n, seg in ((W.INT8, 40000, 50), (W.INT8, 40000, 128), (W.UINT16, 20000, 16), (W.UINT16, 20000, 51),
+                          (W.UINT32, 9000, 7), (W.INT64, 5000, 3), (W.INT64, 5000, 13)):
+        npt = NP_OF[dtype]
+        bits = 8 * np.dtype(npt).itemsize
+        steps = np.repeat(rng.integers(0, 1 << (bits - 1), n // seg + 1, dtype=np.uint64), seg)[:n]
+        v = (steps + rng.integers(0, 1 << min(bits - 2, 11), n, dtype=np.uint64)).astype(W.physical_dtype(dtype)).view(npt)
+        specs = [E.BlockBitPacking(block_size=seg, first_block_rows=max(1, seg // 3))]
+        if dtype in W.INTEGER_TYPES:
+            specs += [E.FOR(frame_size=seg, exact_bits=True), E.FOR(frame_size=seg, first_frame_rows=1)]
+        for spec in specs:
+            encs.append(E.encode(spec, v, dtype))
+            labels.append(f"{W.DATA_TYPE_NAMES[dtype]}/{n}/{spec!r}")
+    check_parity(oracle, encs, labels=labels)
+
+
+def test_blocks_scattered_in_the_payload(gpu, oracle):
+    """Block offsets need not ascend: blocks stored in another order, adjacent
+    (one tile's bytes still fit the staging area) and far apart (they do not)."""
+    rng = np.random.default_rng(161)
+    nb, bs = 8, 1024
+    encs = []
+    for dtype, order in ((W.UINT64, [7, 6, 5, 4, 3, 2, 1, 0]), (W.UINT64, [0, 4, 1, 5, 2, 6, 3, 7]),
+                         (W.UINT32, [3, 7, 0, 4, 1, 5, 2, 6])):
+        npt = NP_OF[dtype]
+        es = np.dtype(npt).itemsize
+        v = rng.integers(0, 1 << 30, nb * bs).astype(npt)
+        raw = [k % 3 == 0 for k in range(nb)]  # every third block raw, the others packed at 30 bits from baseline 0
+        blobs = []
+        for k in range(nb):
+            part = v[k * bs:(k + 1) * bs]
+            blobs.append(part.tobytes() if raw[k] else E.bitpack_variable(part, np.full(bs, 30))[0] + bytes(7))
+        offsets, pos = [0] * nb, 0
+        payload = b""
+        for k in order:  # block k is stored at the position `order` gives it
+            offsets[k] = pos
+            payload += blobs[k]
+            pos += len(blobs[k])
+        widths = [255 if r else 30 for r in raw]
+        enc = (struct.pack("<BBI", W.BLOCK_BIT_PACKING, dtype, nb * bs) + b"\0" + E._write_varint(bs) + E._write_varint(nb) +
+               E._varint_string(_trivial(dtype, [0] * nb)) + E._varint_string(_trivial(W.UINT8, widths)) +
+               E._varint_string(_trivial(W.UINT32, offsets)) + E._write_varint(bs) + payload)
+        assert np.array_equal(oracle.Encoding(enc).materialize(nb * bs), v)
+        encs.append(enc)
+    check_parity(oracle, encs)
+
+
 def _decode_status(enc):
     plan = Plan.from_encodings([enc])
     dec = BatchDecoder(plan)
