@@ -58,10 +58,15 @@ struct Fb {
   Table root() const { return table(rd<uint32_t>(0)); }
   // vector at `pos` (0 = absent): element count and first element
   uint32_t vecLen(uint64_t pos) const { return pos ? rd<uint32_t>(pos) : 0; }
+  // the same, refusing a count whose elements (of `elemBytes` each) would not fit the buffer
+  uint32_t vecLen(uint64_t pos, uint32_t elemBytes) const {
+    const uint32_t len = vecLen(pos);
+    if (len && pos + 4 + (uint64_t)len * elemBytes > n) corrupt("flatbuffer vector beyond end of metadata");
+    return len;
+  }
   template <typename T>
   std::vector<T> scalars(uint64_t pos) const {
-    const uint32_t len = vecLen(pos);
-    if (len && pos + 4 + (uint64_t)len * sizeof(T) > n) corrupt("flatbuffer vector beyond end of metadata");
+    const uint32_t len = vecLen(pos, sizeof(T));
     std::vector<T> v(len);
     if (len) memcpy(v.data(), p + pos + 4, (size_t)len * sizeof(T));
     return v;
@@ -126,8 +131,12 @@ Tablet::Tablet(std::string_view file) : file_(file) {
       if (stripeOffsets_[i] > file_.size() || stripeSizes_[i] > file_.size() - stripeOffsets_[i]) corrupt("stripe outside the file");
   }
   const uint64_t groupsVec = ft.indirect(2);  // Footer.stripe_groups
-  const uint32_t nGroups = footer.vecLen(groupsVec);
+  const uint32_t nGroups = footer.vecLen(groupsVec, 4);
   groups_.resize(nGroups);
+  std::vector<uint32_t> firstStripeOf(nGroups, UINT32_MAX);
+  uint64_t tableEntries = 0;
+  for (uint32_t s = (uint32_t)stripeGroup_.size(); s-- > 0;)
+    if (stripeGroup_[s] < nGroups) firstStripeOf[stripeGroup_[s]] = s;
   for (uint32_t g = 0; g < nGroups; ++g) {
     const Fb sg = sectionBytes(readSection(footer.table(footer.vecOffsetElem(groupsVec, g))), "stripe group");
     if (sg.n >= 8 && memcmp(sg.p + 4, "SGL1", 4) == 0)  // FlatBuffers file identifier of the stream-major layout (StripeGroup.h:66-76)
@@ -138,12 +147,13 @@ Tablet::Tablet(std::string_view file) : file_(file) {
     G.offsets = sg.scalars<uint32_t>(t.indirect(1));
     G.sizes = sg.scalars<uint32_t>(t.indirect(2));
     if (G.offsets.size() != G.sizes.size()) corrupt("stripe group offsets and sizes differ in length");
+    // every entry of a genuine file is stored once: sections shared between groups cannot add up to more than the file
+    tableEntries += G.offsets.size();
+    if (tableEntries * 8 > file_.size()) corrupt("stripe group tables larger than the file");
     if (G.stripeCount == 0 || G.offsets.size() % G.stripeCount) corrupt("stripe group stream table is not stripe_count x stream_count");
     G.streamCount = (uint32_t)(G.offsets.size() / G.stripeCount);
-    bool found = false;
-    for (uint32_t s = 0; s < stripeGroup_.size() && !found; ++s)
-      if (stripeGroup_[s] == g) { G.firstStripe = s; found = true; }
-    if (!found) corrupt("No stripes found for stripe group.");
+    if (firstStripeOf[g] == UINT32_MAX) corrupt("No stripes found for stripe group.");
+    G.firstStripe = firstStripeOf[g];
   }
   for (uint32_t s = 0; s < stripeGroup_.size(); ++s) {
     if (stripeGroup_[s] >= nGroups) corrupt("stripe refers to a missing stripe group");
@@ -156,7 +166,7 @@ Tablet::Tablet(std::string_view file) : file_(file) {
     const auto offsets = footer.scalars<uint64_t>(ot.indirect(1));
     const auto sizes = footer.scalars<uint32_t>(ot.indirect(2));
     const auto comps = footer.scalars<uint8_t>(ot.indirect(3));
-    const uint32_t n = footer.vecLen(names);
+    const uint32_t n = footer.vecLen(names, 4);
     if (offsets.size() != n || sizes.size() != n) corrupt("optional sections vectors differ in length");
     for (uint32_t i = 0; i < n; ++i) {
       const std::string_view name = footer.str(footer.vecOffsetElem(names, i));

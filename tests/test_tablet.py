@@ -68,6 +68,14 @@ def test_tablet_rejects_damage():
             host_shim.Tablet(bytes(bad))
         except host_shim.HostError:
             pass
+    # a count field blown up to ~4 billion elements (vector lengths, stripe-group count) is refused, not allocated
+    for pos in range(len(data) - 400, len(data) - 24, 4):
+        bad = bytearray(data)
+        bad[pos:pos + 4] = (0xFFFFFFF0).to_bytes(4, "little")
+        try:
+            host_shim.Tablet(bytes(bad))
+        except host_shim.HostError:
+            pass
 
 
 @pytest.mark.gpu

@@ -1,0 +1,185 @@
+// Host-only mutation fuzzer for everything in this library that parses
+// untrusted bytes without a GPU: the planner (nbl_plan_batch and the layout /
+// launch queries), the stream splitter, the decompression pre-pass and the file
+// front-end (Tablet).  Meant to be built with the host sanitizers:
+//
+//   python tools/make_corpus.py /tmp/corpus.bin
+//   g++ -std=c++17 -O1 -g -fsanitize=address,undefined -fno-sanitize-recover=undefined -static-libasan \
+//       -Iinclude -Inimble_amd/host tools/plan_fuzz.cpp nimble_amd/csrc/nbl_plan.cpp nimble_amd/csrc/nbl_inflate.cpp \
+//       nimble_amd/host/tablet.cpp -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -L/opt/rocm/lib -lamdhip64 -ldl -lpthread \
+//       -Wl,-rpath,/opt/rocm/lib -o /tmp/plan_fuzz
+//   /tmp/plan_fuzz /tmp/corpus.bin 200000 [seed]
+//
+// Every input lives in a heap block of exactly its size, so a read past the end
+// of a chunk is reported.  Nothing is launched: the kernel launcher is a stub.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <string_view>
+#include <vector>
+
+#include "nimble_amd.h"
+#include "tablet.h"
+
+// the planner object references the launcher; planning never calls it
+namespace nbl { struct KArgs; }
+extern "C" int nbl_launch_kernel(uint32_t, uint32_t, const nbl::KArgs*, void*) { std::abort(); }
+
+namespace {
+struct Entry {
+  uint8_t kind, varint_rows;
+  std::vector<uint8_t> data;
+};
+
+uint64_t rng_state = 88172645463325252ull;
+uint64_t rnd() {
+  rng_state ^= rng_state << 13;
+  rng_state ^= rng_state >> 7;
+  rng_state ^= rng_state << 17;
+  return rng_state;
+}
+uint32_t below(uint32_t n) { return n ? (uint32_t)(rnd() % n) : 0; }
+
+std::vector<uint8_t> mutate(const std::vector<uint8_t>& in) {
+  std::vector<uint8_t> v = in;
+  const uint32_t edits = 1 + below(4);
+  for (uint32_t e = 0; e < edits && !v.empty(); ++e) {
+    // headers sit at the front of every (nested) encoding: bias towards the front half
+    const uint32_t pos = below(3) ? below((uint32_t)v.size() / 2 + 1) % v.size() : below((uint32_t)v.size());
+    switch (below(6)) {
+      case 0: v[pos] = (uint8_t)rnd(); break;
+      case 1: v[pos] ^= (uint8_t)(1u << below(8)); break;
+      case 2: v[pos] = below(2) ? 0xFF : 0x00; break;
+      case 3: v.resize(pos); break;                                            // truncate
+      case 4: v.insert(v.begin() + pos, (uint8_t)rnd()); break;               // shift everything behind
+      case 5:                                                                  // a 4-byte size / count field
+        if (pos + 4 <= v.size()) { const uint32_t x = below(2) ? 0xFFFFFFFFu : (uint32_t)rnd() >> below(32); std::memcpy(&v[pos], &x, 4); }
+        break;
+    }
+  }
+  return v;
+}
+
+struct Counters {
+  uint64_t planned = 0, rejected = 0, inflated = 0, split = 0, tablets = 0;
+} counters;
+
+void one_encoding(const uint8_t* p, uint64_t size, uint32_t varint_rows) {
+  for (uint32_t flags : {0u, NBL_PLAN_PER_KERNEL_LAUNCHES, NBL_PLAN_KEEP_DICTIONARY}) {
+    nbl_options opt{};
+    opt.struct_size = sizeof(opt);
+    opt.use_varint_row_count = varint_rows;
+    opt.flags = flags;
+    const uint64_t off = 0;
+    nbl_plan* plan = nullptr;
+    if (nbl_plan_batch(p, &off, &size, 1, &opt, &plan) != NBL_OK) {
+      ++counters.rejected;
+      if (!nbl_last_error() || !nbl_last_error()[0]) { std::fprintf(stderr, "failure without a message\n"); std::abort(); }
+      continue;
+    }
+    ++counters.planned;
+    nbl_plan_info info{};
+    nbl_plan_get_info(plan, &info);
+    nbl_chunk_layout lay{};
+    nbl_plan_get_chunk_layout(plan, 0, &lay);
+    if (lay.values_offset + lay.values_bytes > info.out_bytes || lay.nulls_offset + lay.nulls_bytes > info.out_bytes ||
+        lay.string_offset + lay.string_bytes > info.out_bytes) {
+      std::fprintf(stderr, "layout outside the output buffer\n");
+      std::abort();
+    }
+    for (uint32_t l = 0; l < info.n_launches; ++l) {
+      nbl_launch_info li{};
+      nbl_plan_get_launch(plan, l, &li);
+    }
+    nbl_plan_free(plan);
+  }
+  nbl_options opt{};
+  opt.struct_size = sizeof(opt);
+  opt.use_varint_row_count = varint_rows;
+  uint64_t need = 0;
+  if (nbl_chunk_inflated_size(p, size, &opt, &need) == NBL_OK && need && need < (64u << 20)) {
+    std::unique_ptr<uint8_t[]> out(new uint8_t[need]);
+    uint64_t got = 0;
+    if (nbl_chunk_inflate(p, size, &opt, out.get(), need, &got) == NBL_OK) {
+      ++counters.inflated;
+      if (got > need) std::abort();
+    }
+  }
+}
+
+void one_stream(const uint8_t* p, uint64_t size) {
+  uint64_t offs[16], sizes[16];
+  uint8_t comp[16];
+  uint32_t n = 0;
+  if (nbl_split_stream_ex(p, size, offs, sizes, comp, 16, &n) == NBL_OK) {
+    ++counters.split;
+    for (uint32_t i = 0; i < n && i < 16; ++i)
+      if (offs[i] + sizes[i] > size) { std::fprintf(stderr, "chunk outside the stream\n"); std::abort(); }
+  }
+  nbl_split_stream(p, size, offs, sizes, 16, &n);
+}
+
+void one_file(const uint8_t* p, uint64_t size) {
+  try {
+    nimble_amd::Tablet t(std::string_view(reinterpret_cast<const char*>(p), size));
+    ++counters.tablets;
+    uint64_t bytes = 0;
+    for (uint32_t s = 0; s < t.stripeCount(); ++s) {
+      const uint32_t n = t.streamCount(s);
+      for (uint32_t id = 0; id < n + 2 && id < 64; ++id) {
+        const std::string_view v = t.stream(s, id);
+        for (char c : v) bytes += (uint8_t)c;  // touch every byte the view claims
+      }
+      t.streams(s);
+    }
+    for (char c : t.optionalSection("columnar.schema")) bytes += (uint8_t)c;
+    (void)bytes;
+  } catch (const nimble_amd::NimbleError&) {
+  }
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+  if (argc < 3) {
+    std::fprintf(stderr, "usage: %s corpus iterations [seed]\n", argv[0]);
+    return 2;
+  }
+  if (argc > 3) rng_state ^= std::strtoull(argv[3], nullptr, 10) * 0x9E3779B97F4A7C15ull;
+  FILE* f = std::fopen(argv[1], "rb");
+  if (!f) return 2;
+  uint32_t count = 0;
+  if (std::fread(&count, 4, 1, f) != 1) return 2;
+  std::vector<Entry> corpus(count);
+  for (auto& e : corpus) {
+    uint32_t size = 0;
+    if (std::fread(&e.kind, 1, 1, f) != 1 || std::fread(&e.varint_rows, 1, 1, f) != 1 || std::fread(&size, 4, 1, f) != 1) return 2;
+    e.data.resize(size);
+    if (size && std::fread(e.data.data(), 1, size, f) != size) return 2;
+  }
+  std::fclose(f);
+  const uint64_t iters = std::strtoull(argv[2], nullptr, 10);
+  for (uint64_t it = 0; it < iters; ++it) {
+    const Entry& e = corpus[below(count)];
+    // the first pass over the corpus runs the seeds unchanged
+    const std::vector<uint8_t> v = it < count ? corpus[it].data : mutate(e.data);
+    const Entry& src = it < count ? corpus[it] : e;
+    std::unique_ptr<uint8_t[]> exact(new uint8_t[v.size() ? v.size() : 1]);
+    if (!v.empty()) std::memcpy(exact.get(), v.data(), v.size());
+    switch (src.kind) {
+      case 0: one_encoding(exact.get(), v.size(), src.varint_rows); break;
+      case 1: one_stream(exact.get(), v.size()); break;
+      default: one_file(exact.get(), v.size()); break;
+    }
+    if ((it + 1) % 20000 == 0)
+      std::printf("%llu inputs: planned %llu rejected %llu inflated %llu split %llu files %llu\n", (unsigned long long)(it + 1),
+                  (unsigned long long)counters.planned, (unsigned long long)counters.rejected, (unsigned long long)counters.inflated,
+                  (unsigned long long)counters.split, (unsigned long long)counters.tablets);
+  }
+  std::printf("done: planned %llu rejected %llu inflated %llu split %llu files %llu\n", (unsigned long long)counters.planned,
+              (unsigned long long)counters.rejected, (unsigned long long)counters.inflated, (unsigned long long)counters.split,
+              (unsigned long long)counters.tablets);
+  return 0;
+}
