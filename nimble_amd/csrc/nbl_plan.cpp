@@ -267,6 +267,11 @@ int nbl_plan::parse(uint64_t off, uint64_t size, int chunk, int depth) {
   const int self = (int)nodes.size();
   nodes.push_back(n);
   auto N = [&]() -> PNode& { return nodes[self]; };
+  // what follows a first child (the next child's prefix) is far from this
+  // header: start fetching it before the first child's subtree is walked
+  auto ahead = [&](uint64_t first_child, uint64_t first_size) {
+    if (first_size < end - first_child) __builtin_prefetch(base + first_child + first_size);
+  };
   auto child = [&](int slot, uint64_t coff, uint64_t csize) {
     NBL_CHECK(coff <= end && csize <= end - coff, "child encoding beyond end of its parent");
     const int c = parse(coff, csize, chunk, depth + 1);
@@ -334,6 +339,7 @@ int nbl_plan::parse(uint64_t off, uint64_t size, int chunk, int depth) {
       NBL_CHECK(pos + 4 <= end, "RLE header beyond end");
       const uint32_t lsize = u32(pos);
       pos += 4;
+      ahead(pos, lsize);
       const int c0 = child(0, pos, lsize);
       NBL_CHECK(is_u32_index_type(nodes[c0].dtype), "RLE run lengths must be uint32");
       pos += lsize;
@@ -353,6 +359,7 @@ int nbl_plan::parse(uint64_t off, uint64_t size, int chunk, int depth) {
       NBL_CHECK(pos + 4 <= end, "Dictionary header beyond end");
       const uint32_t asize = u32(pos);
       pos += 4;
+      ahead(pos, asize);
       const int c0 = child(0, pos, asize);
       NBL_CHECK(nodes[c0].dtype == n.dtype, "Dictionary alphabet has a different data type");
       pos += asize;
@@ -366,6 +373,7 @@ int nbl_plan::parse(uint64_t off, uint64_t size, int chunk, int depth) {
       NBL_CHECK(pos + 4 <= end, "Nullable header beyond end");
       const uint32_t dsize = u32(pos);
       pos += 4;
+      ahead(pos, dsize);
       const int c0 = child(0, pos, dsize);
       NBL_CHECK(nodes[c0].dtype == n.dtype, "Nullable data has a different data type");
       pos += dsize;
@@ -391,6 +399,7 @@ int nbl_plan::parse(uint64_t off, uint64_t size, int chunk, int depth) {
       NBL_CHECK(pos + 4 <= end, "MainlyConstant header beyond end");
       const uint32_t isize = u32(pos);
       pos += 4;
+      ahead(pos, isize);
       const int c0 = child(0, pos, isize);
       NBL_CHECK(nodes[c0].dtype == DT_BOOL && nodes[c0].rows == N().rows, "MainlyConstant isCommon mismatch");
       pos += isize;
@@ -1028,14 +1037,19 @@ nbl_status nbl_plan_batch(const uint8_t* base, const uint64_t* offsets, const ui
     p->keep_dictionary = options && options->struct_size >= 12 && (options->flags & NBL_PLAN_KEEP_DICTIONARY);
     p->layouts.resize(n_chunks);
     for (uint32_t c = 0; c < n_chunks; ++c) p->span = std::max(p->span, offsets[c] + sizes[c]);
-    p->nodes.reserve((size_t)n_chunks * 6);
+    p->nodes.reserve((size_t)n_chunks * 8);
     p->dnodes.reserve((size_t)n_chunks * 4);
     p->aux_in_work.reserve((size_t)n_chunks * 4);
     p->steps.reserve((size_t)n_chunks * 8);
     p->roots.reserve(n_chunks);
     p->chunk_alg.reserve(n_chunks);
     p->chunk_final_step.reserve(n_chunks);
-    for (uint32_t c = 0; c < n_chunks; ++c) p->plan_chunk(c, offsets[c], sizes[c]);
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+      // the headers of a wide table are spread over hundreds of megabytes: have
+      // the prefix of a later chunk on its way while this one is walked
+      if (c + 8 < n_chunks && sizes[c + 8]) __builtin_prefetch(base + offsets[c + 8]);
+      p->plan_chunk(c, offsets[c], sizes[c]);
+    }
     p->finish();
     p->base = nullptr;  // the host bytes are not needed after planning
   } catch (const PlanError& e) {
