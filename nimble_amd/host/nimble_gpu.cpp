@@ -189,16 +189,71 @@ class GpuContext {
 
 namespace {
 
+// The device-to-host copy of a batch's decoded output, issued in slices with an
+// event behind each: the batch is handed out while the copy is still running and
+// an Encoding waits only for the slices its own bytes lie in, so the caller's
+// reads of the first chunks overlap the transfer of the later ones.  Owns the
+// pinned block: it goes back to the pool only after the last slice has landed.
+class OutputCopy {
+ public:
+  explicit OutputCopy(std::shared_ptr<uint8_t> host) : host_(std::move(host)) {}
+  OutputCopy(const OutputCopy&) = delete;
+  OutputCopy& operator=(const OutputCopy&) = delete;
+  ~OutputCopy() {
+    if (!events_.empty()) (void)hipEventSynchronize(events_.back());
+    for (hipEvent_t e : events_) (void)hipEventDestroy(e);
+  }
+  const uint8_t* host() const { return host_.get(); }
+  // enqueues the copy of [0, bytes) on `stream` (the device of the stream is current)
+  void enqueue(const void* dev, uint64_t bytes, hipStream_t stream) {
+    constexpr uint64_t kSlice = 32ull << 20;
+    for (uint64_t off = 0; off < bytes; off += kSlice) {
+      const uint64_t len = std::min(kSlice, bytes - off);
+      hipCheck(hipMemcpyAsync(host_.get() + off, static_cast<const uint8_t*>(dev) + off, len, hipMemcpyDeviceToHost, stream), "D2H");
+      hipEvent_t ev = nullptr;
+      hipCheck(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
+      events_.push_back(ev);
+      ends_.push_back(off + len);
+      hipCheck(hipEventRecord(ev, stream), "hipEventRecord");
+    }
+  }
+  // on return the bytes [0, end) are in host memory
+  void waitFor(uint64_t end) const {
+    if (done_.load(std::memory_order_acquire) >= end || events_.empty()) return;
+    size_t i = 0;
+    while (i + 1 < ends_.size() && ends_[i] < end) ++i;
+    hipCheck(hipEventSynchronize(events_[i]), "D2H");  // slices complete in stream order
+    uint64_t seen = done_.load(std::memory_order_relaxed);
+    while (seen < ends_[i] && !done_.compare_exchange_weak(seen, ends_[i], std::memory_order_release)) {}
+  }
+
+ private:
+  std::shared_ptr<uint8_t> host_;
+  std::vector<hipEvent_t> events_;
+  std::vector<uint64_t> ends_;
+  mutable std::atomic<uint64_t> done_{0};
+};
+
 // One decoded chunk resident in host memory: a window into the batch's pinned
 // output block, which every Encoding of the batch keeps alive (no per-chunk copy).
 class GpuEncoding final : public Encoding {
  public:
-  GpuEncoding(const nbl_chunk_layout& lay, std::shared_ptr<uint8_t> block, const GpuEncodingFactory::StringBufferFactory& sbf)
+  GpuEncoding(const nbl_chunk_layout& lay, std::shared_ptr<const OutputCopy> block, const GpuEncodingFactory::StringBufferFactory& sbf)
       : lay_(lay), block_(std::move(block)) {
     es_ = lay.elem_bytes;
-    const uint8_t* hostOut = block_.get();
+    const uint8_t* hostOut = block_->host();
     values_ = hostOut + lay.values_offset;
     nulls_ = lay.nullable ? hostOut + lay.nulls_offset : nullptr;
+    // the last byte of the output block this chunk reads
+    end_ = lay.values_offset + lay.values_bytes;
+    if (lay.nullable) end_ = std::max(end_, lay.nulls_offset + lay.nulls_bytes);
+    end_ = std::max(end_, lay.string_offset + lay.string_bytes);
+    if (lay.has_dictionary) {
+      end_ = std::max(end_, lay.dict_alphabet_offset + (uint64_t)lay.dict_size * lay.elem_bytes);
+      if (lay.dict_indices_rows) end_ = std::max(end_, lay.dict_indices_offset + lay.dict_indices_rows * 4);
+    }
+    // strings and dictionaries are read right here; plain columns wait at their first read
+    if (lay.data_type == (uint8_t)DataType::String || lay.has_dictionary) arrived();
     if (lay.data_type == (uint8_t)DataType::String) {
       // string bytes live in memory the caller's factory hands out, as the
       // reference's string encodings do (TrivialEncoding.cpp:129-135)
@@ -242,6 +297,7 @@ class GpuEncoding final : public Encoding {
   void materializeIndices(uint32_t n, uint32_t* buffer) override {
     if (!dictIndices_) return Encoding::materializeIndices(n, buffer);
     const uint32_t r = advance(n);
+    arrived();
     memcpy(buffer, dictIndices_ + r, (size_t)n * sizeof(uint32_t));
   }
   EncodingType encodingType() const override { return static_cast<EncodingType>(lay_.encoding_type); }
@@ -254,6 +310,7 @@ class GpuEncoding final : public Encoding {
 
   void materialize(uint32_t n, void* buffer) override {
     const uint32_t r = advance(n);
+    arrived();
     copyRows(r, n, buffer, 0);
   }
 
@@ -262,6 +319,7 @@ class GpuEncoding final : public Encoding {
     const uint32_t r = advance(n);
     const uint32_t scatterSize = scatter ? scatter->size - offset : n;
     if (scatterSize < n) throw NimbleError(NBL_ERR_ARGUMENT, "Scattered output must have at least rowCount positions");
+    arrived();
     if (!lay_.nullable) {  // TypedEncoding::materializeNullable, Encoding.h:412-460
       if (scatterSize == n) {
         copyRows(r, n, buffer, offset);
@@ -306,12 +364,14 @@ class GpuEncoding final : public Encoding {
   void materializeBoolsAsBits(uint32_t n, uint64_t* buffer, int begin) override {
     if (lay_.data_type != (uint8_t)DataType::Bool) throw NimbleError(NBL_ERR_ARGUMENT, "materializeBoolsAsBits on a non-bool encoding");
     const uint32_t r = advance(n);
+    arrived();
     for (uint32_t i = 0; i < n; ++i) values_[r + i] ? bitSet(buffer, (uint64_t)begin + i) : bitClear(buffer, (uint64_t)begin + i);
   }
 
   // cursor-free read of rows [offset, offset + length), for EncodingView
   void readRows(uint32_t offset, uint32_t length, void* buffer) const {
     if (offset > lay_.rows || length > lay_.rows - offset) throw NimbleError(NBL_ERR_ARGUMENT, "read range beyond the row count");
+    arrived();
     copyRows(offset, length, buffer, 0);
   }
 
@@ -344,8 +404,12 @@ class GpuEncoding final : public Encoding {
     memcpy(static_cast<uint8_t*>(buffer) + (size_t)slot * es_, values_ + (size_t)r * es_, (size_t)n * es_);
   }
 
+  // blocks until this chunk's part of the output block has arrived in host memory
+  void arrived() const { block_->waitFor(end_); }
+
   nbl_chunk_layout lay_;
-  std::shared_ptr<uint8_t> block_;
+  std::shared_ptr<const OutputCopy> block_;
+  uint64_t end_ = 0;
   uint32_t es_ = 0;
   uint32_t row_ = 0;
   const uint8_t* values_ = nullptr;
@@ -444,7 +508,7 @@ std::vector<std::unique_ptr<Encoding>> decodeChunks(GpuContext& ctx, const std::
   nbl_plan_info info;
   check(nbl_plan_get_info(plan.p, &info));
 
-  std::shared_ptr<uint8_t> hostOut = ctx.pinned->acquire(info.out_bytes);
+  auto hostOut = std::make_shared<OutputCopy>(ctx.pinned->acquire(info.out_bytes));
   {
     std::lock_guard<std::mutex> lock(ctx.mu);
     ctx.ensure();
@@ -454,8 +518,11 @@ std::vector<std::unique_ptr<Encoding>> decodeChunks(GpuContext& ctx, const std::
     hipCheck(hipMemcpyAsync(ctx.arena.ptr, staging.get(), total, hipMemcpyHostToDevice, ctx.stream_), "H2D");
     check(nbl_plan_upload(plan.p, ctx.work.ptr, ctx.stream_));
     check(nbl_decode_batch_device(plan.p, ctx.arena.ptr, ctx.out.ptr, ctx.work.ptr, ctx.stream_));
-    hipCheck(hipMemcpyAsync(hostOut.get(), ctx.out.ptr, info.out_bytes, hipMemcpyDeviceToHost, ctx.stream_), "D2H");
-    check(nbl_decode_status(plan.p, ctx.work.ptr, ctx.stream_));  // synchronises the stream
+    // synchronises the stream: inconsistent payloads are reported before anything is handed out
+    check(nbl_decode_status(plan.p, ctx.work.ptr, ctx.stream_));
+    // the copy back runs on while the caller already reads the first chunks; a
+    // later batch of this context queues behind it on the same stream
+    hostOut->enqueue(ctx.out.ptr, info.out_bytes, ctx.stream_);
   }
   result.reserve(chunks.size());
   for (uint32_t c = 0; c < chunks.size(); ++c) {

@@ -3,10 +3,15 @@
 // build:  g++ -O2 -std=c++17 -Iinclude -Inimble_amd/host tools/host_bench.cpp -o tools/bin/host_bench \
 //             -Lnimble_amd/_lib -lnimble_amd_host -lnimble_amd -Wl,-rpath,'$ORIGIN/../../nimble_amd/_lib'
 // input:  tools/dump_workload.py <workload> <prefix>  ->  <prefix>.bin, <prefix>.off
+// usage:  host_bench <prefix> [iterations] [reader threads]   (readers > 1: the chunks are materialised by that
+//         many threads, each with a buffer of its own, as the reference's field readers run on an executor)
+#include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <algorithm>
 #include <cstdlib>
 #include <memory>
+#include <thread>
 #include <vector>
 
 #include "nimble_gpu.h"
@@ -19,6 +24,7 @@ int main(int argc, char** argv) {
   if (argc < 2) { fprintf(stderr, "usage: host_bench <prefix> [iterations]\n"); return 2; }
   const std::string prefix = argv[1];
   const int iters = argc > 2 ? atoi(argv[2]) : 5;
+  const int readers = argc > 3 ? std::max(1, atoi(argv[3])) : 1;
   std::vector<char> buf;
   std::vector<uint64_t> off;
   {
@@ -47,22 +53,34 @@ int main(int argc, char** argv) {
       const auto t0 = Clock::now();
       auto encs = factory.createBatch(chunks, sbf, factory.options());
       const auto t1 = Clock::now();
-      uint64_t rows = 0, bytes = 0;
-      for (auto& e : encs) {
-        const uint32_t n = e->rowCount();
-        const bool str = e->dataType() == DataType::String;
-        const size_t es = str ? sizeof(std::string_view) : e->dataType() == DataType::Bool ? 1
-                          : (e->dataType() == DataType::Int64 || e->dataType() == DataType::Uint64 || e->dataType() == DataType::Double) ? 8
-                          : (e->dataType() == DataType::Int32 || e->dataType() == DataType::Uint32 || e->dataType() == DataType::Float) ? 4
-                          : (e->dataType() == DataType::Int16 || e->dataType() == DataType::Uint16) ? 2 : 1;
-        if (sink.size() < (size_t)n * es) sink.resize((size_t)n * es);
-        e->materialize(n, sink.data());
-        rows += n;
-        bytes += (uint64_t)n * (str ? 8 : es);
+      std::atomic<uint64_t> rows{0}, bytes{0};
+      std::atomic<size_t> next{0};
+      auto read_chunks = [&](std::vector<uint8_t>& sink) {
+        for (size_t c = next++; c < encs.size(); c = next++) {
+          auto& e = encs[c];
+          const uint32_t n = e->rowCount();
+          const bool str = e->dataType() == DataType::String;
+          const size_t es = str ? sizeof(std::string_view) : e->dataType() == DataType::Bool ? 1
+                            : (e->dataType() == DataType::Int64 || e->dataType() == DataType::Uint64 || e->dataType() == DataType::Double) ? 8
+                            : (e->dataType() == DataType::Int32 || e->dataType() == DataType::Uint32 || e->dataType() == DataType::Float) ? 4
+                            : (e->dataType() == DataType::Int16 || e->dataType() == DataType::Uint16) ? 2 : 1;
+          if (sink.size() < (size_t)n * es) sink.resize((size_t)n * es);
+          e->materialize(n, sink.data());
+          rows += n;
+          bytes += (uint64_t)n * (str ? 8 : es);
+        }
+      };
+      if (readers == 1) {
+        read_chunks(sink);
+      } else {
+        std::vector<std::vector<uint8_t>> sinks((size_t)readers);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < readers; ++t) pool.emplace_back([&, t] { read_chunks(sinks[(size_t)t]); });
+        for (auto& t : pool) t.join();
       }
       const auto t2 = Clock::now();
       printf("iter %d: createBatch %.2f ms  materialize %.2f ms  rows %llu  decoded %.3f GB  end-to-end %.2f GB/s (createBatch only %.2f GB/s)\n", it,
-             ms(t0, t1), ms(t1, t2), (unsigned long long)rows, bytes / 1e9, bytes / 1e6 / ms(t0, t2), bytes / 1e6 / ms(t0, t1));
+             ms(t0, t1), ms(t1, t2), (unsigned long long)rows.load(), bytes.load() / 1e9, bytes.load() / 1e6 / ms(t0, t2), bytes.load() / 1e6 / ms(t0, t1));
     }
   } catch (const std::exception& e) {
     fprintf(stderr, "error: %s\n", e.what());
