@@ -314,3 +314,41 @@ def test_block_encodings_through_the_host_layer(factory):
             check_materialize_patterns(e, phys(data, dtype), dtype, rng)
             e.reset()
             check_scattered_materialize(e, phys(data, dtype), dtype, rng)
+
+
+def test_output_copy_in_slices(factory):
+    """A stripe whose decoded output spans several slices of the copy back to the
+    host: streams read last-first (each waits for its own slices only), a stripe
+    dropped while its copy is still in flight (its pinned block must not be reused
+    before the copy has landed), and a following stripe that reuses the buffers."""
+    import host_shim
+
+    rng = np.random.default_rng(321)
+    rows = 1_500_000  # 12 MB per int64 stream: 9 streams = 108 MB of output, four 32 MiB slices
+
+    def make(seed_shift):
+        cols = [(rng.integers(0, 1 << 40, rows) + seed_shift + i).astype(np.int64) for i in range(9)]
+        streams = [E.stream([E.encode(E.FixedBitWidth(), c[: rows // 2], W.INT64), E.encode(E.Trivial(), c[rows // 2:], W.INT64)])
+                   for c in cols]
+        return cols, streams
+
+    cols_a, streams_a = make(0)
+    cols_b, streams_b = make(7)
+    for _ in range(2):
+        dropped = host_shim.StripeDecoder(factory, streams_a)
+        del dropped  # nothing read: the copy back is still running when the decoders go away
+        stripe = host_shim.StripeDecoder(factory, streams_b)
+        for i in reversed(range(9)):
+            out = np.zeros(rows, dtype=np.int64)
+            nn, _ = stripe.stream(i).next(rows, out)
+            assert nn == rows and np.array_equal(out, cols_b[i]), i
+        stripe2 = host_shim.StripeDecoder(factory, streams_a)  # queued behind the first one on the same stream
+        out = np.zeros(rows, dtype=np.int64)
+        stripe2.stream(4).next(rows, out)
+        assert np.array_equal(out, cols_a[4])
+        out2 = np.zeros(1000, dtype=np.int64)
+        d = stripe.stream(0)
+        d.reset()
+        d.skip(rows - 1000)
+        d.next(1000, out2)
+        assert np.array_equal(out2, cols_b[0][-1000:])
