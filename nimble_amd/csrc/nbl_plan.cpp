@@ -722,11 +722,15 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       alloc_scan(d, nt);
       d.self = nn.is_bool ? bits_ref() : mat_ref(es);
       const uint32_t dn = add_dnode(d);
-      add_step(lvl, K_REDUCE_POPC, 0, dn, div_up32(rows, kBitTileRows));  // each tile emits the partials of kBitTileRows / trows consumer tiles
-      add_step(lvl + 1, K_SCAN_TILES, 0, dn, 1, true);
-      if (nn.is_bool) add_step(lvl + 2, K_SELECT_BITS, 0, dn, nt);
-      else add_step(lvl + 2, K_SELECT_SCATTER, es, dn, nt);
-      nn.ref = d.self; nn.ready = lvl + 3;
+      // the ranks need the selection bitmap only: counted and scanned as soon as
+      // that child is ready, underneath whatever the values child still has to do
+      const int sel_lvl = (nullable ? C(1) : C(0)).ready;
+      const int fin = std::max(lvl, sel_lvl + 2);
+      add_step(sel_lvl, K_REDUCE_POPC, 0, dn, div_up32(rows, kBitTileRows));  // each tile emits the partials of kBitTileRows / trows consumer tiles
+      add_step(sel_lvl + 1, K_SCAN_TILES, 0, dn, 1, true);
+      if (nn.is_bool) add_step(fin, K_SELECT_BITS, 0, dn, nt);
+      else add_step(fin, K_SELECT_SCATTER, es, dn, nt);
+      nn.ref = d.self; nn.ready = fin + 1;
       break;
     }
     case ET_BLOCKBITPACKING:
