@@ -194,3 +194,24 @@ def test_leaf_only_chunks_fill_the_preparatory_levels():
     only_deep = Plan.from_encodings(deep)
     assert [l[2] for l in only_deep.launches()][1] == 1  # the scan level alone is one workgroup
     p.close(); only_deep.close()
+
+
+def test_rank_counting_is_placed_at_the_bitmap_level():
+    """The popcount partials and their scan of a Nullable read the null bitmap
+    only: under a deep values child (RLE: sums, scan, run ends, expand) they run
+    alongside its first steps, and the rank scatter is the single extra level."""
+    rng = np.random.default_rng(5)
+    n = 300_000
+    mask = rng.random(n) < 0.7
+    v = np.repeat(rng.integers(0, 90, n // 10 + 1), 10)[: int(mask.sum())].astype(np.int64)
+    enc = E.encode_nullable(E.Nullable(data=E.RLE(), nulls=E.Trivial()), v, mask, W.INT64)
+    p = Plan.from_encodings([enc], per_kernel=True)
+    level = {}
+    for name, _, _, lvl, _ in p.launches():
+        level.setdefault(name, lvl)
+    assert level["k_reduce_popc"] == level["k_reduce_sum"] == 0
+    assert level["k_rle_expand<8>"] == 3 and level["k_select_scatter<8>"] == 4
+    p.close()
+    fused = Plan.from_encodings([enc])
+    assert int(fused.info.n_launches) == 5
+    fused.close()
