@@ -86,7 +86,10 @@ class Plan:
             self._h = None
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:  # interpreter shutdown: the ctypes module may be gone already
+            pass
 
 
 class BatchDecoder:
