@@ -1069,13 +1069,18 @@ __device__ __forceinline__ void body_rle_expand_bool(const KArgs& a, const NodeD
 // SparseBoolEncoding::materializeBoolsAsBits (encodings/SparseBoolEncoding.cpp:121-142):
 // every row is !sparseValue except the listed (ascending) positions.
 __device__ __forceinline__ void body_sparse_bits(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
-  constexpr uint32_t W = kBitTileWords;
+  // A tile is 65536 rows (8 KiB of bitmap, four words per thread): the two
+  // searches for the tile's range of positions are a chain of dependent loads
+  // and the output is tiny, so few large tiles beat many small ones.
+  constexpr uint32_t W = kSparseTileWords;
+  constexpr uint32_t WPT = W / kBlock;
+  static_assert(W % kBlock == 0 && W * 8 + 8 <= kSmemBytes, "sparse tile geometry");
   uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem);
-  uint32_t* s_k = reinterpret_cast<uint32_t*>(smem + 2048);
+  uint32_t* s_k = reinterpret_cast<uint32_t*>(smem + W * 8);
   const uint64_t rows = nd.rows;
   const uint32_t K = nd.c0.rows;
-  const uint64_t p0 = (uint64_t)tile * kBitTileRows;
-  const uint64_t p1 = p0 + kBitTileRows < rows ? p0 + kBitTileRows : rows;
+  const uint64_t p0 = (uint64_t)tile * kSparseTileRows;
+  const uint64_t p1 = p0 + kSparseTileRows < rows ? p0 + kSparseTileRows : rows;
   uint64_t* dst = reinterpret_cast<uint64_t*>(a.work + nd.self.off);
   with_reader<4>(nd.c0, a, [&](auto rd) {
     if (wave_id() == 0) {
@@ -1087,7 +1092,8 @@ __device__ __forceinline__ void body_sparse_bits(const KArgs& a, const NodeDesc&
       uint32_t k = wave_first_true(K, [&](uint32_t i) { return rd.get(i) >= key; });
       if (lane_id() == 0) s_k[1] = k;
     }
-    s_bits[threadIdx.x] = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < WPT; ++u) s_bits[u * kBlock + threadIdx.x] = 0;
     __syncthreads();
     const uint32_t lo = s_k[0], hi = s_k[1];
     uint32_t* bits32 = reinterpret_cast<uint32_t*>(s_bits);
@@ -1110,12 +1116,15 @@ __device__ __forceinline__ void body_sparse_bits(const KArgs& a, const NodeDesc&
     }
   });
   __syncthreads();
-  const uint64_t w = (uint64_t)tile * W + threadIdx.x;
-  if (w * 64 < rows) {
-    uint64_t v = s_bits[threadIdx.x];
-    if (!(nd.flags & NF_SPARSE_VALUE)) v = ~v;
-    if (w * 64 + 64 > rows) v &= wmask((uint32_t)(rows - w * 64));
-    dst[w] = v;
+#pragma unroll
+  for (uint32_t u = 0; u < WPT; ++u) {
+    const uint64_t w = (uint64_t)tile * W + u * kBlock + threadIdx.x;
+    if (w * 64 < rows) {
+      uint64_t v = s_bits[u * kBlock + threadIdx.x];
+      if (!(nd.flags & NF_SPARSE_VALUE)) v = ~v;
+      if (w * 64 + 64 > rows) v &= wmask((uint32_t)(rows - w * 64));
+      dst[w] = v;
+    }
   }
 }
 

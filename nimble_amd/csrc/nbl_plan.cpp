@@ -652,7 +652,7 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       d.rows = rows;
       if (nn.flag) d.flags |= NF_SPARSE_VALUE;
       const uint32_t dn = add_dnode(d);
-      add_step(lvl, K_SPARSE_BITS, 0, dn, div_up32(rows, kBitTileRows));
+      add_step(lvl, K_SPARSE_BITS, 0, dn, div_up32(rows, kSparseTileRows));
       nn.ref = d.self; nn.ready = lvl + 1;
       break;
     }
