@@ -150,6 +150,8 @@ constexpr uint32_t kTileBytes = 16384;
 constexpr uint32_t kScanTile = 2048;        // elements per tile of the u32 scans
 constexpr uint32_t kBitTileWords = 256;     // 64-bit words per bitmap tile (16384 rows)
 constexpr uint32_t kBitTileRows = kBitTileWords * 64;
+constexpr uint32_t kPopcWordsPerThread = 4;  // K_REDUCE_POPC: bitmap words per thread
+constexpr uint32_t kPopcTileRows = kBitTileRows * kPopcWordsPerThread;
 constexpr uint32_t kSparseTileWords = 1024;  // words per tile of the positions -> bitmap step (65536 rows)
 constexpr uint32_t kSparseTileRows = kSparseTileWords * 64;
 constexpr uint32_t kVarintTile = 4096;      // encoded bytes per varint tile

@@ -721,24 +721,35 @@ __device__ __forceinline__ void body_reduce_sum(const KArgs& a, const NodeDesc& 
 }
 
 // Set bits of the selection bitmap per consumer tile.  One workgroup counts
-// kBitTileRows rows (one 64-bit word per thread) and emits one partial per
-// consumer tile of nd.aux2 rows (32, 64, 128 or 256 words).
+// kPopcTileRows rows (kPopcWordsPerThread 64-bit words per thread, all loaded
+// before the first is counted) and emits one partial per consumer tile of
+// nd.aux2 rows (32, 64, 128 or 256 words).
 __device__ __forceinline__ void body_reduce_popc(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
   uint32_t* tmp = reinterpret_cast<uint32_t*>(smem);
   const uint32_t sub = (uint32_t)(nd.aux2 >> 6);  // words per consumer tile
-  const uint64_t w = (uint64_t)tile * kBitTileWords + threadIdx.x;
-  const bool live = w * 64 < nd.sel.rows;
-  uint32_t s = live ? (uint32_t)__popcll(bits_word_masked(nd.sel, a, w, (nd.flags & NF_INVERT_SEL) != 0)) : 0u;
+  const bool invert = (nd.flags & NF_INVERT_SEL) != 0;
+  uint32_t cnt[kPopcWordsPerThread];
 #pragma unroll
-  for (int d = 16; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);  // sum of the aligned 32-lane group
-  if (sub >= 64) s += __shfl_xor(s, 32, 64);                    // sum of the wave
-  if (sub > 64) {
-    __syncthreads();
-    if (lane_id() == 0) tmp[wave_id()] = s;
-    __syncthreads();
-    s = sub == 128 ? tmp[wave_id() & 2u] + tmp[(wave_id() & 2u) + 1] : tmp[0] + tmp[1] + tmp[2] + tmp[3];
+  for (uint32_t u = 0; u < kPopcWordsPerThread; ++u) {
+    const uint64_t w = ((uint64_t)tile * kPopcWordsPerThread + u) * kBitTileWords + threadIdx.x;
+    cnt[u] = w * 64 < nd.sel.rows ? (uint32_t)__popcll(bits_word_masked(nd.sel, a, w, invert)) : 0u;
   }
-  if (live && (threadIdx.x & (sub - 1)) == 0) a.parts[nd.part_base + (uint32_t)(w / sub)] = s;
+#pragma unroll
+  for (uint32_t u = 0; u < kPopcWordsPerThread; ++u) {
+    const uint64_t w = ((uint64_t)tile * kPopcWordsPerThread + u) * kBitTileWords + threadIdx.x;
+    const bool live = w * 64 < nd.sel.rows;
+    uint32_t s = cnt[u];
+#pragma unroll
+    for (int d = 16; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);  // sum of the aligned 32-lane group
+    if (sub >= 64) s += __shfl_xor(s, 32, 64);                    // sum of the wave
+    if (sub > 64) {
+      __syncthreads();
+      if (lane_id() == 0) tmp[wave_id()] = s;
+      __syncthreads();
+      s = sub == 128 ? tmp[wave_id() & 2u] + tmp[(wave_id() & 2u) + 1] : tmp[0] + tmp[1] + tmp[2] + tmp[3];
+    }
+    if (live && (threadIdx.x & (sub - 1)) == 0) a.parts[nd.part_base + (uint32_t)(w / sub)] = s;
+  }
 }
 
 // A varint starts at payload byte b when b == 0 or byte b-1 has its high bit

@@ -726,7 +726,7 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       // that child is ready, underneath whatever the values child still has to do
       const int sel_lvl = (nullable ? C(1) : C(0)).ready;
       const int fin = std::max(lvl, sel_lvl + 2);
-      add_step(sel_lvl, K_REDUCE_POPC, 0, dn, div_up32(rows, kBitTileRows));  // each tile emits the partials of kBitTileRows / trows consumer tiles
+      add_step(sel_lvl, K_REDUCE_POPC, 0, dn, div_up32(rows, kPopcTileRows));  // each tile emits the partials of kPopcTileRows / trows consumer tiles
       add_step(sel_lvl + 1, K_SCAN_TILES, 0, dn, 1, true);
       if (nn.is_bool) add_step(fin, K_SELECT_BITS, 0, dn, nt);
       else add_step(fin, K_SELECT_SCATTER, es, dn, nt);
