@@ -128,6 +128,10 @@ typedef struct nbl_chunk_layout {
  * (dwio/nimble/common/ChunkHeader.h:28-40); use nbl_split_stream first.
  * Replaces the recursive constructor walk of EncodingFactory::create.
  */
+/* The (offset, size) pairs are trusted to lie inside the caller's buffer: the
+ * library is not told its length.  A pair whose sum overflows is refused
+ * (NBL_ERR_ARGUMENT); every bound inside a chunk is checked against the
+ * chunk's own size. */
 nbl_status nbl_plan_batch(const uint8_t* base, const uint64_t* offsets,
                           const uint64_t* sizes, uint32_t n_chunks,
                           const nbl_options* options, nbl_plan** plan_out);
@@ -179,7 +183,11 @@ nbl_status nbl_chunk_inflate(const uint8_t* chunk, uint64_t size, const nbl_opti
 
 /* Copies the plan's descriptor tables to the front of `d_work`
  * (info.descriptor_bytes, asynchronous on `stream`).  Must precede
- * nbl_decode_batch_device on the same stream for a given d_work. */
+ * nbl_decode_batch_device on the same stream for a given d_work.
+ * Lifetime: the copy reads host memory the plan owns, and it is asynchronous,
+ * so the plan must stay alive until `stream` has passed the upload (and the
+ * decodes that use it): synchronise the stream -- nbl_decode_status does --
+ * before nbl_plan_free. */
 nbl_status nbl_plan_upload(nbl_plan* plan, void* d_work, void* stream);
 
 /*

@@ -21,6 +21,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 
 #include "../../include/nimble_amd.h"
 
@@ -107,6 +108,11 @@ void payload_inflate(uint8_t ct, const uint8_t* data, uint64_t size, uint8_t* ou
 struct Walker {
   bool varint_rows;
   bool any_compressed = false;
+  // Rewritten sizes of the children that are preceded by a varint size field
+  // (the block encodings' per-segment arrays), keyed by the child's address:
+  // the size has to be known before the child is written, and sizing a child by
+  // walking it again at every level would cost 2^depth walks on a nested chain.
+  std::unordered_map<const uint8_t*, uint64_t> sized;
 
   // Size of the rewritten encoding [p, p+size); when out != nullptr also writes it.
   uint64_t rewrite(const uint8_t* p, uint64_t size, uint8_t* out, int depth) {
@@ -177,10 +183,20 @@ struct Walker {
     auto varint_child = [&]() {
       const uint32_t csize = read_varint();
       INF_CHECK(csize <= size - pos, "child encoding beyond end of its parent");
-      const uint64_t n = rewrite(p + pos, csize, nullptr, depth + 1);
-      INF_CHECK(n <= 0xFFFFFFFFull, "rewritten child exceeds 4 GiB");
-      write_varint((uint32_t)n);
-      child(pos, csize);
+      uint64_t n;
+      if (!out) {  // sizing pass: one walk of the child, remembered for the writing pass
+        n = rewrite(p + pos, csize, nullptr, depth + 1);
+        sized[p + pos] = n;
+        INF_CHECK(n <= 0xFFFFFFFFull, "rewritten child exceeds 4 GiB");
+        write_varint((uint32_t)n);
+        o += n;
+      } else {
+        const auto it = sized.find(p + pos);
+        n = it != sized.end() ? it->second : rewrite(p + pos, csize, nullptr, depth + 1);
+        INF_CHECK(n <= 0xFFFFFFFFull, "rewritten child exceeds 4 GiB");
+        write_varint((uint32_t)n);
+        child(pos, csize);
+      }
       pos += csize;
     };
     copy(p, prefix);
@@ -294,7 +310,10 @@ nbl_status nbl_uncompress(uint8_t compression, const uint8_t* data, uint64_t siz
 }
 
 nbl_status nbl_chunk_inflated_size(const uint8_t* chunk, uint64_t size, const nbl_options* options, uint64_t* out_size) {
-  if (!chunk || !out_size) { nbl_set_last_error("null argument"); return NBL_ERR_ARGUMENT; }
+  if (!out_size) { nbl_set_last_error("null argument"); return NBL_ERR_ARGUMENT; }
+  // an empty chunk is malformed Nimble, whatever its pointer (EncodingFactory::create reads the prefix first)
+  if (size == 0) { nbl_set_last_error("encoding shorter than its prefix"); return NBL_ERR_CORRUPT; }
+  if (!chunk) { nbl_set_last_error("null argument"); return NBL_ERR_ARGUMENT; }
   return guarded([&] {
     Walker w{options && options->struct_size >= 8 && options->use_varint_row_count != 0};
     const uint64_t n = w.rewrite(chunk, size, nullptr, 0);

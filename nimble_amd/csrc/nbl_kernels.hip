@@ -853,12 +853,13 @@ __device__ __forceinline__ void body_rle_ends(const KArgs& a, const NodeDesc& nd
   uint32_t* first_run = rle_first_run(a, nd);
   const uint32_t tile_rows = (uint32_t)nd.aux2;
   const uint64_t rows = nd.rows;
+  if (rows == 0) return;  // no output tile, so no first_run entry exists (the planner schedules nothing for such a node)
   uint32_t start = ex;
 #pragma unroll
   for (uint32_t j = 0; j < 8; ++j) {
     const uint32_t end = v[j] + ex;
     if (e0 + j < n && end > start) {  // wrapped sums (corrupt lengths) have end <= start and write nothing
-      const uint64_t last_row = (uint64_t)end - 1 < rows ? (uint64_t)end - 1 : rows - 1;
+      const uint64_t last_row = (uint64_t)end - 1 < rows ? (uint64_t)end - 1 : rows - 1;  // < rows: t_hi stays inside first_run[]
       const uint32_t t_hi = (uint32_t)(last_row / tile_rows);
 #pragma unroll 1
       for (uint32_t t = (uint32_t)(((uint64_t)start + tile_rows - 1) / tile_rows); t <= t_hi; ++t) first_run[t] = (uint32_t)(e0 + j);

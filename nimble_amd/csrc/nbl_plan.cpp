@@ -618,6 +618,18 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       break;
     }
     case ET_RLE: {
+      if (rows == 0) {
+        // Nothing to expand whatever the run children hold (the reference reads a
+        // run only when a row asks for one, RLEEncoding.h:289-301): an empty column,
+        // no kernels.
+        ColRef r{};
+        if (nn.is_bool) { r.kind = COL_BITS_WORK; r.off = alloc_work(0); }
+        else if (root) { r = *root_dst; }
+        else { r.kind = COL_MAT_WORK; r.off = alloc_work(0); }
+        r.rows = 0; r.es = nn.is_bool ? 0 : (uint8_t)es;
+        nn.ref = r; nn.ready = lvl;
+        break;
+      }
       NodeDesc d{};
       d.c0 = C(0).ref;
       d.rows = rows;
@@ -1040,7 +1052,10 @@ nbl_status nbl_plan_batch(const uint8_t* base, const uint64_t* offsets, const ui
     p->fused = !(options && options->struct_size >= 12 && (options->flags & NBL_PLAN_PER_KERNEL_LAUNCHES));
     p->keep_dictionary = options && options->struct_size >= 12 && (options->flags & NBL_PLAN_KEEP_DICTIONARY);
     p->layouts.resize(n_chunks);
-    for (uint32_t c = 0; c < n_chunks; ++c) p->span = std::max(p->span, offsets[c] + sizes[c]);
+    for (uint32_t c = 0; c < n_chunks; ++c) {
+      if (offsets[c] + sizes[c] < offsets[c]) fail(NBL_ERR_ARGUMENT, "chunk %u: offset + size overflows", c);
+      p->span = std::max(p->span, offsets[c] + sizes[c]);
+    }
     p->nodes.reserve((size_t)n_chunks * 8);
     p->dnodes.reserve((size_t)n_chunks * 4);
     p->aux_in_work.reserve((size_t)n_chunks * 4);
@@ -1221,11 +1236,15 @@ static nbl_status decode_impl(const nbl_plan* p, nbl_profile* prof, uint32_t ste
     a.tiles = tiles + L.tile_begin;
     a.tile_aux = tile_aux + L.tile_begin;
     a.n_tiles = L.n_tiles;
-    if (prof && (li == 0 || prof->group_of[li] != prof->group_of[li - 1]))
-      (void)hipEventRecord(prof->events[(size_t)step * (prof->n_groups + 1) + prof->group_of[li]], static_cast<hipStream_t>(stream));
+    if (prof && (li == 0 || prof->group_of[li] != prof->group_of[li - 1])) {
+      e = hipEventRecord(prof->events[(size_t)step * (prof->n_groups + 1) + prof->group_of[li]], static_cast<hipStream_t>(stream));
+      if (e != hipSuccess) return hip_fail("hipEventRecord", e);
+    }
     const int rc = nbl_launch_kernel(L.kernel, L.es, &a, stream);
-    if (prof && li + 1 == nl)
-      (void)hipEventRecord(prof->events[(size_t)step * (prof->n_groups + 1) + prof->n_groups], static_cast<hipStream_t>(stream));
+    if (prof && li + 1 == nl) {
+      e = hipEventRecord(prof->events[(size_t)step * (prof->n_groups + 1) + prof->n_groups], static_cast<hipStream_t>(stream));
+      if (e != hipSuccess) return hip_fail("hipEventRecord", e);
+    }
     if (rc != 0) {
       g_last_error = "launch of " + L.name + " failed";
       return NBL_ERR_HIP;

@@ -215,3 +215,43 @@ def test_rank_counting_is_placed_at_the_bitmap_level():
     fused = Plan.from_encodings([enc])
     assert int(fused.info.n_launches) == 5
     fused.close()
+
+
+def _rle_bytes(dtype, rows, lengths, values, varint_rows=False):
+    lens = E.encode(E.Trivial(), np.asarray(lengths, dtype=np.uint32), W.UINT32, varint_rows)
+    vals = E.encode(E.Trivial(), np.asarray(values).astype(W.physical_dtype(dtype)), dtype, varint_rows)
+    return E.prefix(W.RLE, dtype, rows, varint_rows) + struct.pack("<I", len(lens)) + lens + vals
+
+
+def empty_rle_cases(varint_rows=False):
+    """An RLE node whose row count is 0 while its run-length child is not empty:
+    as a root, as the values child of an all-null Nullable, and as a bool column."""
+    root = _rle_bytes(W.INT64, 0, [5], [7], varint_rows)
+    nulls = E.encode(E.Trivial(), np.zeros(3000, dtype=bool), W.BOOL, varint_rows)
+    data = _rle_bytes(W.INT32, 0, [5, 9], [7, 8], varint_rows)
+    under = E.prefix(W.NULLABLE, W.INT32, 3000, varint_rows) + struct.pack("<I", len(data)) + data + nulls
+    lens = E.encode(E.Trivial(), np.asarray([4, 4], dtype=np.uint32), W.UINT32, varint_rows)
+    boolean = E.prefix(W.RLE, W.BOOL, 0, varint_rows) + struct.pack("<I", len(lens)) + lens + b"\x01"
+    return [root, under, boolean]
+
+
+@pytest.mark.parametrize("varint_rows", [False, True])
+def test_rle_without_rows_schedules_no_run_kernels(varint_rows):
+    """rowCount 0 over non-empty run lengths (one damaged byte away under varint
+    row counts): nothing is expanded, so no run-end / expand step may be planned
+    -- the run-end kernel's per-tile table has no entry for such a node."""
+    for per_kernel in (False, True):
+        p = Plan.from_encodings(empty_rle_cases(varint_rows), varint_rows, per_kernel=per_kernel)
+        names = {l[0] for l in p.launches()}
+        assert not any(n.startswith(("k_rle", "k_reduce_sum")) for n in names), names
+        assert [l.rows for l in p.layouts] == [0, 3000, 0]
+        p.close()
+
+
+def test_chunk_offsets_that_overflow_are_refused():
+    enc = E.encode(E.Trivial(), np.arange(4, dtype=np.int32), W.INT32)
+    buf = capi.as_u8(enc)
+    offs, sizes = np.array([2**64 - 8], dtype=np.uint64), np.array([len(enc)], dtype=np.uint64)
+    plan = C.c_void_p()
+    st = capi.lib().nbl_plan_batch(buf.ctypes.data, offs.ctypes.data, sizes.ctypes.data, 1, None, C.byref(plan))
+    assert st == capi.NBL_ERR_ARGUMENT and b"overflows" in capi.lib().nbl_last_error()

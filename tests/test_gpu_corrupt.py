@@ -135,3 +135,15 @@ def test_empty_chunks(gpu, oracle):
     ]
     res = check_parity(oracle, encs)
     assert [r.rows for r in res] == [0] * 10 + [7]
+
+
+@pytest.mark.parametrize("varint_rows", [False, True])
+def test_rle_without_rows_over_non_empty_run_lengths(gpu, oracle, varint_rows):
+    """rowCount 0 with run lengths present (root, values child of an all-null
+    Nullable, bool): decodes to empty / all-null columns like the oracle, and a
+    populated neighbour in the same batch is unaffected."""
+    from test_capi_cpu import empty_rle_cases
+
+    neighbour = E.encode(E.RLE(), np.repeat(np.arange(50, dtype=np.int64), 40), W.INT64, varint_rows)
+    res = check_parity(oracle, empty_rle_cases(varint_rows) + [neighbour], varint_rows)
+    assert [r.rows for r in res] == [0, 3000, 0, 2000]

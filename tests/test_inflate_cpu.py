@@ -104,3 +104,40 @@ def test_whole_chunk_compression_and_damage():
             pass
     with pytest.raises(capi.NimbleUnsupportedError, match="compression type"):
         capi.inflate_chunk(enc[:6] + bytes([4]) + enc[7:])  # OpenZL
+
+
+def _varint(v):
+    out = bytearray()
+    while v >= 128:
+        out.append(128 | (v & 127))
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def test_nested_block_encodings_are_sized_once():
+    """A chain of BlockBitPacking encodings nested through the baselines child,
+    31 deep: the rewritten size of every varint-sized child is computed by ONE
+    walk, so the pre-pass stays linear in the chunk (sizing each child by
+    walking it again at every level would take 2^31 walks here)."""
+    import time
+
+    small = E.encode(E.Trivial(), np.zeros(1, dtype=np.uint8), W.UINT8)
+    offs = E.encode(E.Trivial(), np.zeros(1, dtype=np.uint32), W.UINT32)
+    enc = E.encode(E.Trivial(compression="zstd"), np.arange(64, dtype=np.int64), W.INT64)
+    plain = E.encode(E.Trivial(), np.arange(64, dtype=np.int64), W.INT64)
+
+    def wrap(child):
+        return (E.prefix(W.BLOCK_BIT_PACKING, W.INT64, 1) + bytes([W.UNCOMPRESSED]) + _varint(1) + _varint(1)
+                + _varint(len(child)) + child + _varint(len(small)) + small + _varint(len(offs)) + offs + _varint(1) + bytes(8))
+
+    for _ in range(30):
+        enc, plain = wrap(enc), wrap(plain)
+    t0 = time.perf_counter()
+    assert capi.inflate_chunk(enc) == plain
+    assert time.perf_counter() - t0 < 1.0
+
+
+def test_empty_chunk_is_corrupt_not_a_bad_argument():
+    need = C.c_uint64(0)
+    assert capi.lib().nbl_chunk_inflated_size(None, 0, None, C.byref(need)) == capi.NBL_ERR_CORRUPT
