@@ -1,19 +1,31 @@
 #!/usr/bin/env python3
-"""Headline benchmark: device-resident decode of the "10M-row int32/int64
-columns, fixed-bit-width + RLE cascades" table.
+"""Benchmark of the device-resident cascade decode.
 
-One step = one pass of the decode path over the whole batch (every chunk of every
-column of a 10M-row stripe), inputs and descriptor tables already resident in
-HBM.  Stripes are independent, so with N GPUs every rank decodes its own stripe
-(weak scaling, no data-path collective; a barrier brackets the timed region).
+Headline (default): the "10M-row int32/int64 columns, fixed-bit-width + RLE
+cascades" table.  One step = one pass of the decode path over every chunk of
+every column of the rank's stripe(s), inputs and descriptor tables already
+resident in HBM.
+
+Multi-GPU: stripes are independent, so ranks never exchange data; a barrier
+brackets the timed region and the elapsed time is the MAX over ranks.
+  --scaling weak   (default) every rank decodes one stripe of identical shape
+  --scaling strong a fixed table (mixed: 8 stripes, wide: 16 stripes) is dealt
+                   over the ranks with shard.assign_stripes; a step is one pass
+                   over the whole table
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts N rank
+processes itself (fresh children, before this process touches the GPU) and
+relays rank 0's line; under torchrun the ranks are taken from the environment.
 
 Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,42 +36,128 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+DEFAULT_ROWS = {"fbw_rle": 10_000_000, "dict_string": 10_000_000, "mixed": 1_250_000, "wide": 100_000}
+STRONG_STRIPES = {"mixed": 8, "wide": 16}  # stripes of the fixed tables
+WORKLOAD_TEXT = {
+    "fbw_rle": "{rows}-row int32/int64 columns, fixed-bit-width + RLE cascades "
+               "(8 int32 + 16 int64 FBW widths, 4 RLE columns; <=20MiB raw chunks)",
+    "dict_string": "{rows}-row dictionary-encoded string columns (3 alphabet sizes x 3 null fractions) with nullable wrapper",
+    "mixed": "mixed-type 100-column table, 3-level cascades, {rows}-row stripes",
+    "wide": "wide ML table, 5000 sparse/nullable float columns, {rows}-row stripes",
+}
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=0, help="rows per column (default: the workload's own size)")
-    ap.add_argument("--workload", default="fbw_rle", choices=["fbw_rle", "dict_string", "mixed", "wide"],
+    ap.add_argument("--rows", type=int, default=0, help="rows per stripe (default: the workload's own size)")
+    ap.add_argument("--workload", default="fbw_rle", choices=list(DEFAULT_ROWS),
                     help="fbw_rle is the headline configuration; the others are the remaining benchmark tables")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="strong: the fixed 8-stripe (mixed) / 16-stripe (wide) table dealt over the ranks")
+    ap.add_argument("--stripes", type=int, default=0, help="strong scaling: stripes of the table (default 8 mixed / 16 wide)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the H2D+decode+D2H measurement")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the per-operation profile of the unfused plan")
-    ap.add_argument("--cpu-sample-chunks", type=int, default=0, help="0 = first chunk of every column")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the short runs of the other benchmark tables")
     ap.add_argument("--check", action="store_true", help="verify a sample of the output against the oracle")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)")
-    return ap.parse_args()
+    ap.add_argument("--rank-probe", action="store_true",
+                    help="launcher self-check: every rank joins the process group, nothing touches a GPU")
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(chunks, min_seconds=12.0):
+# ----------------------------------------------------------------- launcher
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def rank_commands(n: int, argv, port: int, base_env=None):
+    """(argv, env) of the N rank processes `--gpus N` starts: this script again,
+    one process per GPU, rendezvous on 127.0.0.1."""
+    out = []
+    for r in range(n):
+        env = dict(base_env if base_env is not None else os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        out.append(([sys.executable, "-u", os.path.abspath(__file__)] + list(argv), env))
+    return out
+
+
+def launch_ranks(n: int, argv) -> int:
+    """Parent of a `--gpus N` run: starts the ranks as fresh child processes (this
+    process has made no GPU call and makes none), relays rank 0's JSON line and
+    returns non-zero when any rank failed.  The children are ended by PID if one
+    of them dies."""
+    procs = []
+    for r, (cmd, env) in enumerate(rank_commands(n, argv, free_port())):
+        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = b""
+    rc = 0
+    try:
+        out0, _ = procs[0].communicate()
+        for p in procs:
+            p.wait()
+            rc = rc or p.returncode
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    lines = [l for l in out0.decode(errors="replace").splitlines() if l.strip()]
+    for l in lines[:-1]:
+        print(l, file=sys.stderr)
+    if lines:
+        print(lines[-1])
+    return rc
+
+
+def rank_probe(world: int, rank: int) -> None:
+    import torch
+    import torch.distributed as dist
+
+    dist.init_process_group(backend="gloo")
+    t = torch.tensor([rank + 1], dtype=torch.int64)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"n_gpus": world, "rank_sum": int(t.item()), "probe": True}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+# ------------------------------------------------------------- CPU baseline
+_ES_OF = {1: 1, 2: 1, 3: 2, 4: 2, 5: 4, 6: 4, 7: 8, 8: 8, 9: 4, 10: 8, 11: 1, 12: 16}
+
+
+def _chunk_meta(chunks):
+    arrays = [np.frombuffer(enc, dtype=np.uint8) for _, enc in chunks]
+    meta = [(int(np.frombuffer(enc[2:6], dtype=np.uint32)[0]), _ES_OF[enc[1]]) for _, enc in chunks]
+    return arrays, meta
+
+
+def cpu_baseline(chunks, min_seconds=10.0, fast=True):
     """Times the CPU oracle (a port of the reference decode) on ONE thread over a
     bounded sample: whole passes over the same chunks the GPU decodes, repeated
-    until at least `min_seconds` of CPU work (the output buffer is reused)."""
+    until at least `min_seconds` of CPU work.  `fast` selects the oracle's
+    bench-only bulk path (64-value unrolled unpack groups and run fills, the
+    shape of FixedBitArray::bulkGet32Internal / bulkGet64WithBaseline and
+    RLEEncoding::materialize's simdFill); without it every value goes through
+    the element-wise get, which understates the reference."""
     from oracle import oracle as O
 
     lib = O.lib()
-    arrays = [np.frombuffer(enc, dtype=np.uint8) for _, enc in chunks]
-    es_of = {1: 1, 2: 1, 3: 2, 4: 2, 5: 4, 6: 4, 7: 8, 8: 8, 9: 4, 10: 8, 11: 1, 12: 16}
-    meta = [(int(np.frombuffer(enc[2:6], dtype=np.uint32)[0]), es_of[enc[1]]) for _, enc in chunks]
+    decode = lib.orc_decode_all_fast if fast else lib.orc_decode_all
+    arrays, meta = _chunk_meta(chunks)
     vals = np.zeros(max(n * es for n, es in meta) + 64, dtype=np.uint8)
     out_bytes = rows = passes = 0
     t0 = time.perf_counter()
     while True:
         for a, (n, es) in zip(arrays, meta):
-            r = lib.orc_decode_all(a.ctypes.data, a.size, 0, vals.ctypes.data, None)
+            r = decode(a.ctypes.data, a.size, 0, vals.ctypes.data, None)
             if r == 0xFFFFFFFF:
                 raise RuntimeError("oracle failed to decode a benchmark chunk")
             out_bytes += n * es
@@ -70,37 +168,40 @@ def cpu_baseline(chunks, min_seconds=12.0):
     dt = time.perf_counter() - t0
     return {
         "value": round(out_bytes / dt / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
+        "path": "bulk (64-value unrolled groups)" if fast else "element-wise get",
         "sample": f"{passes} full pass(es) over the same {len(chunks)} chunks ({rows} rows, {out_bytes} decoded bytes, "
-                  f"{dt:.1f} s, single thread, oracle/nimble_oracle.c -O3 -march=native)",
+                  f"{dt:.1f} s, single thread, oracle/nimble_oracle.c -O3 -march=native; one output buffer reused, "
+                  f"so stores mostly stay in cache: leans in the CPU's favour)",
         "rows_per_s": round(rows / dt),
     }
 
 
 def cpu_baseline_threads(chunks, threads, min_seconds=8.0):
-    """The same oracle on `threads` host threads, one chunk per task (chunks are
-    independent, as columns and stripes are for the reference's reader).  The
+    """The oracle's bulk path on `threads` host threads, one chunk per task
+    (chunks are independent, as columns and stripes are for the reference's
+    reader).  Every chunk is decoded into an output region of its own, as a
+    reader materialising the table would, so the stores go to memory.  The
     oracle calls run outside the GIL."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle as O
 
     lib = O.lib()
-    arrays = [np.frombuffer(enc, dtype=np.uint8) for _, enc in chunks]
-    es_of = {1: 1, 2: 1, 3: 2, 4: 2, 5: 4, 6: 4, 7: 8, 8: 8, 9: 4, 10: 8, 11: 1, 12: 16}
-    meta = [(int(np.frombuffer(enc[2:6], dtype=np.uint32)[0]), es_of[enc[1]]) for _, enc in chunks]
-    biggest = max(n * es for n, es in meta) + 64
+    arrays, meta = _chunk_meta(chunks)
+    offs = np.zeros(len(meta) + 1, dtype=np.int64)
+    np.cumsum([((n * es + 64 + 63) // 64) * 64 for n, es in meta], out=offs[1:])
+    out = np.zeros(int(offs[-1]), dtype=np.uint8)
     deadline = [0.0]
 
     def worker(t):
-        vals = np.zeros(biggest, dtype=np.uint8)
-        out = rows = 0
+        done = rows = 0
         while True:
             for i in range(t, len(arrays), threads):
-                if lib.orc_decode_all(arrays[i].ctypes.data, arrays[i].size, 0, vals.ctypes.data, None) == 0xFFFFFFFF:
+                if lib.orc_decode_all_fast(arrays[i].ctypes.data, arrays[i].size, 0, out.ctypes.data + int(offs[i]), None) == 0xFFFFFFFF:
                     raise RuntimeError("oracle failed to decode a benchmark chunk")
-                out += meta[i][0] * meta[i][1]
+                done += meta[i][0] * meta[i][1]
                 rows += meta[i][0]
             if time.perf_counter() >= deadline[0]:
-                return out, rows
+                return done, rows
 
     t0 = time.perf_counter()
     deadline[0] = t0 + min_seconds
@@ -109,11 +210,13 @@ def cpu_baseline_threads(chunks, threads, min_seconds=8.0):
     dt = time.perf_counter() - t0
     out_bytes, rows = sum(p[0] for p in parts), sum(p[1] for p in parts)
     return {"value": round(out_bytes / dt / 1e9, 3), "unit": "GB/s", "cores": threads, "kind": "port",
+            "path": "bulk (64-value unrolled groups)",
             "sample": f"{threads} threads, each looping over its share of the same {len(chunks)} chunks for {dt:.1f} s "
-                      f"({rows} rows, {out_bytes} decoded bytes)",
+                      f"({rows} rows, {out_bytes} decoded bytes; every chunk has its own output region, {out.size} bytes in all)",
             "rows_per_s": round(rows / dt)}
 
 
+# ------------------------------------------------------------ GPU-side legs
 def copy_ceiling(torch, device, nbytes=1 << 31, reps=10):
     """In-run achievable HBM rate: a device-to-device copy of `nbytes` (bytes read + bytes written per second)."""
     src = torch.empty(nbytes, dtype=torch.uint8, device=device)
@@ -194,16 +297,149 @@ def pcie_pipelined(plan, torch, device, n_buffers=2, stripes=8):
             "stripes": stripes, "h2d_gbs": round(enc / dt / 1e9, 2), "d2h_gbs": round(int(plan.info.out_bytes) / dt / 1e9, 2)}
 
 
+class Job:
+    """The stripes one rank owns, planned and resident on its GPU."""
+
+    def __init__(self, workload, rows, stripe_ids, device, per_kernel=False, keep_chunks=False):
+        from nimble_amd import workloads
+        from nimble_amd.decoder import BatchDecoder, Plan
+
+        self.plans, self.decs, self.chunks = [], [], []
+        t0 = time.perf_counter()
+        for s in stripe_ids:
+            chunks = workloads.WORKLOADS[workload](rows, 42 + s)
+            buf, offs = workloads.pack_chunks(chunks)
+            plan = Plan(buf, offs, per_kernel=per_kernel)
+            dec = BatchDecoder(plan, str(device))
+            dec.stage()
+            self.plans.append(plan)
+            self.decs.append(dec)
+            self.chunks.append(chunks if keep_chunks else None)
+        self.gen_seconds = time.perf_counter() - t0
+        self.decoded = sum(int(p.info.decoded_bytes) for p in self.plans)
+        self.encoded = sum(int(p.info.encoded_bytes) for p in self.plans)
+        self.rows = sum(int(p.info.total_rows) for p in self.plans)
+        self.launch_list = [l for p in self.plans for l in p.launches()]
+
+    def decode(self):
+        for d in self.decs:
+            d.decode()
+
+    def status(self):
+        for d in self.decs:
+            d.status()  # also synchronises; raises if a kernel flagged bad data
+
+    def profile_begin(self, steps):
+        for d in self.decs:
+            d.profile_begin(steps)
+
+    def decode_profiled(self, s):
+        for d in self.decs:
+            d.decode_profiled(s)
+
+    def profile_end(self):
+        return [ms for d in self.decs for ms in d.profile_end()]
+
+    def close(self):
+        self.decs.clear()
+        for p in self.plans:
+            p.close()
+
+
+def by_kernel(launch_list, ms_list):
+    by = {}
+    for (name, es, nt, lvl, alg), ms in zip(launch_list, ms_list):
+        k = by.setdefault(name, {"ms": 0.0, "alg": 0, "tiles": 0, "launches": 0})
+        k["ms"] += ms
+        k["alg"] += alg
+        k["tiles"] += nt
+        k["launches"] += 1
+    return by
+
+
+def kernel_table(by):
+    return [
+        {"kernel": k, "ms_per_step": round(v["ms"], 4), "launches": v["launches"], "tiles": v["tiles"],
+         "algorithmic_gbs": round(v["alg"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 and v["alg"] else None}
+        for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])
+    ]
+
+
+def roofline_of(by, workload, rows, launches_per_step_of=1):
+    """Roofline object of the dominant kernel (largest share of device time):
+    achieved = algorithmic bytes per launch / mean launch duration (HIP events on
+    the decode stream); traffic = HBM bytes per launch from the committed PMC
+    passes of the same workload (FETCH_SIZE and WRITE_SIZE collected in separate
+    rocprofv3 runs, corrected by tools/pmc_traffic.py), or null."""
+    dom_key = max(by, key=lambda k: by[k]["ms"])
+    dom = by[dom_key]
+    achieved = dom["alg"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] > 0 else 0.0
+    roofline = {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "kernel": dom_key, "kernel_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
+        "launches_per_step": dom["launches"],
+        "algorithmic_bytes_per_launch": dom["alg"] // max(dom["launches"], 1),
+    }
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
+        pmc = json.load(open(path))
+        k = pmc.get("kernels", {}).get(dom_key)
+        if pmc.get("rows") == rows and pmc.get("workload", "fbw_rle") == workload and k:
+            roofline["traffic"] = k["traffic_bytes"]
+            roofline["traffic_over_algorithmic"] = round(k["traffic_bytes"] / max(roofline["algorithmic_bytes_per_launch"], 1), 4)
+            roofline["traffic_source"] = os.path.relpath(path, ROOT)
+            break
+    return roofline
+
+
+def short_run(workload, rows, device, torch, steps=5, warmup=2):
+    """One of the other benchmark tables, outside the headline's timed region:
+    `steps` passes over one stripe, wall clock between device synchronisations,
+    per-launch HIP events for the roofline of its dominant kernel."""
+    job = Job(workload, rows, [0], device)
+    for _ in range(warmup):
+        job.decode()
+    job.status()
+    job.profile_begin(steps)
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for s in range(steps):
+        job.decode_profiled(s)
+    torch.cuda.synchronize(device)
+    dt = (time.perf_counter() - t0) / steps
+    ms = job.profile_end()
+    job.status()
+    by = by_kernel(job.launch_list, ms)
+    whole = (job.encoded + job.decoded) / (sum(ms) * 1e-3) / 1e9 if sum(ms) > 0 else 0.0
+    res = {
+        "workload": WORKLOAD_TEXT[workload].format(rows=rows), "value": round(job.decoded / dt / 1e9, 2), "unit": "GB/s",
+        "ms_per_step": round(dt * 1e3, 4), "steps": steps, "rows_per_s": round(job.rows / dt),
+        "decoded_bytes": job.decoded, "encoded_bytes": job.encoded, "chunks": len(job.plans[0].layouts),
+        "launches_per_step": len(job.launch_list),
+        "whole_batch_algorithmic_gbs": round(whole, 1), "whole_batch_hbm_frac": round(whole / HBM_PEAK_GBS, 4),
+        "roofline": roofline_of(by, workload, rows), "kernels": kernel_table(by), "gen_seconds": round(job.gen_seconds, 1),
+    }
+    job.close()
+    return res
+
+
 def main():
     args = parse_args()
-    import torch
-    import torch.distributed as dist
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    world = int(world_env or "1")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if args.rank_probe:
+        return rank_probe(world, rank)
+
+    import torch
+    import torch.distributed as dist
+
+    if world > 1:
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
         else:
@@ -213,128 +449,95 @@ def main():
     device = torch.device(f"cuda:{local_rank}")
     torch.cuda.set_device(device)
 
-    from nimble_amd import shard, workloads
-    from nimble_amd.decoder import BatchDecoder, Plan
+    from nimble_amd import shard
 
-    t_gen = time.perf_counter()
-    # one stripe of identical shape per GPU (weak scaling); ownership by the same
-    # assignment a file reader uses, computed on every rank without communication
-    default_rows = {"fbw_rle": 10_000_000, "dict_string": 10_000_000, "mixed": 1_250_000, "wide": 100_000}
-    args.rows = args.rows or default_rows[args.workload]
-    stripe = shard.assign_stripes([args.rows] * n_gpus, n_gpus)[rank][0]
-    chunks = workloads.WORKLOADS[args.workload](args.rows, 42 + stripe)
-    buf, offs = workloads.pack_chunks(chunks)
-    t_gen = time.perf_counter() - t_gen
-    plan = Plan(buf, offs)
-    dec = BatchDecoder(plan, str(device))
-    dec.stage()
-    info = plan.info
-    launches = plan.launches()
+    args.rows = args.rows or DEFAULT_ROWS[args.workload]
+    if args.scaling == "strong":
+        if args.workload not in STRONG_STRIPES:
+            raise SystemExit("--scaling strong is defined for the fixed tables: --workload mixed | wide")
+        n_stripes = args.stripes or STRONG_STRIPES[args.workload]
+    else:
+        n_stripes = n_gpus  # one stripe of identical shape per GPU
+    # ownership by the assignment a file reader uses (longest-processing-time over the
+    # footer's stripe sizes; the synthetic stripes have one shape, so one size),
+    # computed on every rank without communication
+    owned = shard.assign_stripes([args.rows] * n_stripes, n_gpus)[rank]
+    job = Job(args.workload, args.rows, owned, device, keep_chunks=(rank == 0))
 
     for _ in range(args.warmup):
-        dec.decode()
-    dec.status()  # also synchronises; raises if a kernel flagged bad data
+        job.decode()
+    job.status()
 
     # timed region: exactly K steps between barrier + device synchronise on both
     # sides, max over ranks; per-launch HIP events recorded on the decode stream
-    dec.profile_begin(args.steps)
+    job.profile_begin(args.steps)
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
 
     def step(s):
         if s == 0:
             ev0.record()
-        dec.decode_profiled(s)
+        job.decode_profiled(s)
         if s == args.steps - 1:
             ev1.record()
 
     elapsed = shard.timed_steps(step, args.steps, lambda: torch.cuda.synchronize(device), dist if world > 1 else None)
-    dev_ms = ev0.elapsed_time(ev1)
-    launch_ms = dec.profile_end()
-    dec.status()
+    dev_ms = ev0.elapsed_time(ev1) if owned else 0.0
+    launch_ms = job.profile_end()
+    job.status()
 
-    decoded = int(info.decoded_bytes)
-    rows = int(info.total_rows)
-    total_decoded = decoded * n_gpus  # every rank decodes a stripe of identical shape
+    totals = [job.decoded, job.rows, job.encoded]
+    if world > 1:  # whole-job totals (ranks may own different stripes): one scalar reduction, outside the timed region
+        t = torch.tensor(totals, dtype=torch.int64)
+        if args.backend == "nccl":
+            t = t.to(device)
+        dist.all_reduce(t)
+        totals = [int(x) for x in t.tolist()]
+    total_decoded, total_rows, total_encoded = totals
     ms_per_step = elapsed / args.steps * 1e3
     value = total_decoded * args.steps / elapsed / 1e9
 
-    # roofline of the dominant kernel (largest share of device time)
-    def group(launch_list, ms_list):
-        by = {}
-        for (name, es, nt, lvl, alg), ms in zip(launch_list, ms_list):
-            k = by.setdefault(name, {"ms": 0.0, "alg": 0, "tiles": 0, "launches": 0})
-            k["ms"] += ms
-            k["alg"] += alg
-            k["tiles"] += nt
-            k["launches"] += 1
-        return by
-
-    def table(by):
-        return [
-            {"kernel": k, "ms_per_step": round(v["ms"], 4), "launches": v["launches"], "tiles": v["tiles"],
-             "algorithmic_gbs": round(v["alg"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 and v["alg"] else None}
-            for k, v in sorted(by.items(), key=lambda kv: -kv[1]["ms"])
-        ]
-
-    by_kernel = group(launches, launch_ms)
-    dom_key = max(by_kernel, key=lambda k: by_kernel[k]["ms"])
-    dom = by_kernel[dom_key]
-    achieved = dom["alg"] / (dom["ms"] * 1e-3) / 1e9 if dom["ms"] > 0 else 0.0
-    roofline = {
-        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-        "kernel": dom_key, "kernel_ms": round(dom["ms"] / max(dom["launches"], 1), 4),
-        "algorithmic_bytes_per_launch": dom["alg"] // max(dom["launches"], 1),
-    }
-    # HBM bytes per launch from the PMC passes of this same command (FETCH_SIZE and
-    # WRITE_SIZE collected in separate rocprofv3 runs, corrected by tools/pmc_traffic.py)
-    import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
-        pmc = json.load(open(path))
-        k = pmc.get("kernels", {}).get(roofline["kernel"])
-        if pmc.get("rows") == args.rows and pmc.get("workload", "fbw_rle") == args.workload and k:
-            roofline["traffic"] = k["traffic_bytes"]
-            roofline["traffic_over_algorithmic"] = round(k["traffic_bytes"] / max(roofline["algorithmic_bytes_per_launch"], 1), 4)
-            roofline["traffic_source"] = os.path.relpath(path, ROOT)
-            break
-    whole = (int(info.encoded_bytes) + decoded) / (sum(launch_ms) * 1e-3) / 1e9 if sum(launch_ms) > 0 else 0.0
-    if rank == 0:
+    by = by_kernel(job.launch_list, launch_ms)
+    roofline = roofline_of(by, args.workload, args.rows) if by else None
+    whole = (job.encoded + job.decoded) / (sum(launch_ms) * 1e-3) / 1e9 if sum(launch_ms) > 0 else 0.0
+    if rank == 0 and roofline is not None:
         # second denominator: what a plain device-to-device copy sustains on this GPU in this run
         ceiling = copy_ceiling(torch, device)
         roofline["copy_ceiling_gbs"] = round(ceiling, 1)
-        roofline["frac_of_copy_ceiling"] = round(achieved / ceiling, 4) if ceiling > 0 else None
+        roofline["frac_of_copy_ceiling"] = round(roofline["achieved"] / ceiling, 4) if ceiling > 0 else None
 
+    text = WORKLOAD_TEXT[args.workload].format(rows=args.rows)
+    text += f"; {n_stripes} stripes dealt over {n_gpus} GPU(s)" if args.scaling == "strong" else "; one stripe per GPU"
     result = {
         "metric": "device-resident decoded GB/s (output bytes) per GPU and per 8xMI355X node",
         "value": round(value, 2), "unit": "GB/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "u64", "data": "synthetic",
         "config": {
-            "workload": {
-                "fbw_rle": f"{args.rows // 1_000_000}M-row int32/int64 columns, fixed-bit-width + RLE cascades "
-                           f"(8 int32 + 16 int64 FBW widths, 4 RLE columns; <=20MiB raw chunks; one stripe per GPU)",
-                "dict_string": f"{args.rows}-row dictionary-encoded string columns (3 alphabet sizes) with nullable wrapper",
-                "mixed": f"mixed-type 100-column table, 3-level cascades, one {args.rows}-row stripe per GPU",
-                "wide": f"wide ML table, 5000 sparse/nullable float columns, one {args.rows}-row stripe per GPU",
-            }[args.workload],
-            "rows_per_gpu": args.rows, "chunks_per_gpu": int(info.n_chunks), "nodes_per_gpu": int(info.n_nodes),
-            "launches_per_step": int(info.n_launches), "parallelism": f"stripe-sharded x{n_gpus}",
+            "workload": text, "rows_per_stripe": args.rows, "stripes": n_stripes, "stripes_on_rank0": len(owned),
+            "chunks_on_rank0": sum(len(p.layouts) for p in job.plans),
+            "nodes_on_rank0": sum(int(p.info.n_nodes) for p in job.plans),
+            "launches_per_step_on_rank0": len(job.launch_list), "parallelism": f"stripe-sharded x{n_gpus}",
+            "backend": (args.backend if world > 1 else None),
         },
-        "rows_per_s": round(rows * n_gpus * args.steps / elapsed),
-        "decoded_bytes_per_gpu": decoded, "encoded_bytes_per_gpu": int(info.encoded_bytes),
+        "rows_per_s": round(total_rows * args.steps / elapsed),
+        "decoded_bytes_total": total_decoded, "encoded_bytes_total": total_encoded,
+        "decoded_bytes_rank0": job.decoded, "encoded_bytes_rank0": job.encoded,
         "device_ms_per_step": round(dev_ms / args.steps, 4),
         "whole_batch_algorithmic_gbs": round(whole, 1),
         "whole_batch_hbm_frac": round(whole / HBM_PEAK_GBS, 4),
         "roofline": roofline,
-        "kernels": table(by_kernel),
-        "gen_seconds": round(t_gen, 1),
+        "kernels": kernel_table(by),
+        "gen_seconds": round(job.gen_seconds, 1),
     }
 
-    if rank == 0 and n_gpus == 1 and not args.no_breakdown:
+    solo = rank == 0 and n_gpus == 1 and len(job.plans) == 1
+    if solo and not args.no_breakdown:
         # diagnostic, outside the timed region: the same batch with one launch per
         # (level, operation), which attributes device time to operations
-        plan2 = Plan(buf, offs, per_kernel=True)
+        from nimble_amd.decoder import BatchDecoder, Plan
+
+        plan2 = Plan(job.plans[0].buffer, job.plans[0].chunks, per_kernel=True)
         dec2 = BatchDecoder(plan2, str(device))
         dec2.stage()
         for _ in range(2):
@@ -345,28 +548,36 @@ def main():
             dec2.decode_profiled(s)
         ms2 = dec2.profile_end()
         result["per_operation"] = {"launches_per_step": int(plan2.info.n_launches), "sum_ms_per_step": round(sum(ms2), 4),
-                                   "kernels": table(group(plan2.launches(), ms2))}
+                                   "kernels": kernel_table(by_kernel(plan2.launches(), ms2))}
         del dec2
         plan2.close()
 
-    if args.check and rank == 0:
+    if args.check and rank == 0 and job.plans:
         from oracle import oracle as O
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         from util import assert_chunk_equal, oracle_chunk
         from nimble_amd.decoder import slice_chunk
-        host = dec.out.cpu().numpy()
+        host = job.decs[0].out.cpu().numpy()
+        chunks = job.chunks[0]
         for i in range(0, len(chunks), 7):
-            assert_chunk_equal(slice_chunk(host, plan.layouts[i]), oracle_chunk(O, chunks[i][1]), chunks[i][0])
+            assert_chunk_equal(slice_chunk(host, job.plans[0].layouts[i]), oracle_chunk(O, chunks[i][1]), chunks[i][0])
         result["checked_chunks"] = len(range(0, len(chunks), 7))
 
-    if rank == 0 and n_gpus == 1 and not args.no_pcie:
-        result["pcie_inclusive"] = pcie_inclusive(dec, plan, torch, device)
-        result["pcie_pipelined"] = pcie_pipelined(plan, torch, device)
-    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+    if solo and not args.no_pcie:
+        result["pcie_inclusive"] = pcie_inclusive(job.decs[0], job.plans[0], torch, device)
+        result["pcie_pipelined"] = pcie_pipelined(job.plans[0], torch, device)
+    if solo and not args.no_cpu_baseline:
+        chunks = job.chunks[0]
         result["cpu_baseline"] = cpu_baseline(chunks, min_seconds=10.0)
+        result["cpu_baseline_elementwise"] = cpu_baseline(chunks, min_seconds=4.0, fast=False)
         # the GPU box gives this job 16 host threads (OMP_NUM_THREADS is set to that share)
         threads = max(1, min(int(os.environ.get("OMP_NUM_THREADS", "0") or 0) or (os.cpu_count() or 1), 16, len(chunks)))
         result["cpu_baseline_all_cores"] = cpu_baseline_threads(chunks, threads)
+    if solo and args.workload == "fbw_rle" and not args.no_other_workloads:
+        job.close()
+        del job
+        torch.cuda.empty_cache()
+        result["other_workloads"] = {w: short_run(w, DEFAULT_ROWS[w], device, torch) for w in ("dict_string", "mixed", "wide")}
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -11,7 +11,12 @@
  *   prefix parse ............ encodings/common/EncodingPrefix.h:65-92,
  *                             encodings/common/Encoding.cpp:22-33
  *   factory dispatch ........ encodings/common/EncodingFactory.cpp:62-164
- *   FixedBitArray get ....... common/FixedBitArray.cpp:41-57,221-326,426-508
+ *   FixedBitArray get ....... common/FixedBitArray.cpp:41-57 (every value through get();
+ *                             the checker's path)
+ *   FixedBitArray bulk ...... common/FixedBitArray.cpp:114-156,221-326,345-358,426-508,
+ *                             common/FixedBitArray.h:104-138 (64-value groups per bit
+ *                             width etc.; same results, selected by orc_set_bulk /
+ *                             orc_decode_all_fast for the CPU baseline's timing only)
  *   FixedBitWidth ........... encodings/FixedBitWidthEncoding.h:149-192
  *   Trivial numeric ......... encodings/TrivialEncoding.h:252-300
  *   Trivial bool / string ... encodings/TrivialEncoding.cpp:101-164,291-381
@@ -81,6 +86,7 @@ typedef struct { const char* ptr; uint64_t len; } orc_sv;
 
 typedef struct orc_ctx {
   int varint_rows;           /* Encoding::Options::useVarintRowCount */
+  int bulk;                  /* FixedBitWidth reads through the bulk path below (same results; CPU baseline timing) */
   char err[256];
   jmp_buf jb;
   void** allocs;             /* string buffers handed out by the factory */
@@ -240,9 +246,137 @@ static inline uint64_t fba_get(const orc_enc* e, uint64_t index) {  /* FixedBitA
   return (word >> rem) & e->mask;
 }
 
+/* ---- FixedBitArray bulk reads ----------------------------------------------
+ * The shape of the reference's fast path, for the CPU baseline's timing: every
+ * 64 values end on a word boundary, so after aligning with single gets the
+ * values are unpacked in groups of 64 by code specialised per bit width
+ * (bulkGet32Internal, FixedBitArray.cpp:114-156,221-326); 8-byte outputs of
+ * width >= 32 take the byte-aligned loads (:345-358,438-463), one unaligned
+ * word per value up to 58 bits (:478-488) and the two-word stitch above that
+ * (:490-507).  Results are identical to fba_get + baseline (checked by
+ * tests/test_oracle_semantics.py); only the instruction mix differs. */
+#define FBA_GROUP64(NAME, T)                                                                                     \
+  static inline __attribute__((always_inline)) void NAME(const uint8_t* src, T* out, T base, const int w) {      \
+    uint64_t words[33];                                                                                          \
+    memcpy(words, src, (size_t)8 * (size_t)w);                                                                   \
+    words[w] = 0;                                                                                                \
+    const uint64_t mask = (1ull << w) - 1ull;                                                                    \
+    _Pragma("GCC unroll 64")                                                                                     \
+    for (int i = 0; i < 64; ++i) {                                                                               \
+      const int bit = i * w, wi = bit >> 6, sh = bit & 63;                                                       \
+      uint64_t v = words[wi] >> sh;                                                                              \
+      if (sh + w > 64) v |= words[wi + 1] << (64 - sh);                                                          \
+      out[i] = (T)((T)(v & mask) + base);                                                                        \
+    }                                                                                                            \
+  }
+FBA_GROUP64(fba_group64_u32, uint32_t)
+FBA_GROUP64(fba_group64_u64, uint64_t)
+#undef FBA_GROUP64
+#define FBA_CASE(W, FN) case W: for (uint64_t g = 0; g < groups; ++g) FN(src + g * 8 * W, out + g * 64, base, W); break;
+#define FBA_CASES(FN)                                                                                              \
+  FBA_CASE(1, FN) FBA_CASE(2, FN) FBA_CASE(3, FN) FBA_CASE(4, FN) FBA_CASE(5, FN) FBA_CASE(6, FN) FBA_CASE(7, FN)    \
+  FBA_CASE(8, FN) FBA_CASE(9, FN) FBA_CASE(10, FN) FBA_CASE(11, FN) FBA_CASE(12, FN) FBA_CASE(13, FN)               \
+  FBA_CASE(14, FN) FBA_CASE(15, FN) FBA_CASE(16, FN) FBA_CASE(17, FN) FBA_CASE(18, FN) FBA_CASE(19, FN)             \
+  FBA_CASE(20, FN) FBA_CASE(21, FN) FBA_CASE(22, FN) FBA_CASE(23, FN) FBA_CASE(24, FN) FBA_CASE(25, FN)             \
+  FBA_CASE(26, FN) FBA_CASE(27, FN) FBA_CASE(28, FN) FBA_CASE(29, FN) FBA_CASE(30, FN) FBA_CASE(31, FN)             \
+  FBA_CASE(32, FN)
+static void fba_groups_u32(const uint8_t* src, uint32_t* out, uint32_t base, int w, uint64_t groups) {
+  switch (w) { FBA_CASES(fba_group64_u32) default: break; }
+}
+static void fba_groups_u64(const uint8_t* src, uint64_t* out, uint64_t base, int w, uint64_t groups) {
+  switch (w) { FBA_CASES(fba_group64_u64) default: break; }
+}
+#undef FBA_CASES
+#undef FBA_CASE
+/* bulkGet32Internal<uint32_t, true> (w in [1, 32]) */
+static void fba_bulk32(const orc_enc* e, uint64_t start, uint64_t length, uint32_t* values, uint32_t base) {
+  const uint64_t aligned = (start + 63) / 64 * 64;
+  if (start + length < aligned) {
+    for (uint64_t i = start; i < start + length; ++i) *values++ = (uint32_t)fba_get(e, i) + base;
+    return;
+  }
+  for (uint64_t i = start; i < aligned; ++i) *values++ = (uint32_t)fba_get(e, i) + base;
+  const uint64_t groups = (length - (aligned - start)) >> 6;
+  fba_groups_u32(e->payload + ((aligned * (uint64_t)e->bit_width) >> 3), values, base, e->bit_width, groups);
+  values += groups << 6;
+  for (uint64_t i = aligned + (groups << 6); i < start + length; ++i) *values++ = (uint32_t)fba_get(e, i) + base;
+}
+/* bulkGet64WithBaseline */
+static void fba_bulk64(const orc_enc* e, uint64_t start, uint64_t length, uint64_t* values, uint64_t base) {
+  const int w = e->bit_width;
+  if (w < 32) {  /* bulkGetWithBaseline32Into64 */
+    const uint64_t aligned = (start + 63) / 64 * 64;
+    if (start + length < aligned) {
+      for (uint64_t i = start; i < start + length; ++i) *values++ = fba_get(e, i) + base;
+      return;
+    }
+    for (uint64_t i = start; i < aligned; ++i) *values++ = fba_get(e, i) + base;
+    const uint64_t groups = (length - (aligned - start)) >> 6;
+    fba_groups_u64(e->payload + ((aligned * (uint64_t)w) >> 3), values, base, w, groups);
+    values += groups << 6;
+    for (uint64_t i = aligned + (groups << 6); i < start + length; ++i) *values++ = fba_get(e, i) + base;
+    return;
+  }
+  if ((w & 7) == 0) {  /* 32, 40, 48, 56, 64: byte-aligned residuals */
+    const int bw = w >> 3;
+    const uint8_t* next = e->payload + start * (uint64_t)bw;
+    if (bw == 4) { for (uint64_t i = 0; i < length; ++i, next += 4) { uint32_t v; memcpy(&v, next, 4); values[i] = (uint64_t)v + base; } }
+    else if (bw == 8) { for (uint64_t i = 0; i < length; ++i, next += 8) { uint64_t v; memcpy(&v, next, 8); values[i] = v + base; } }
+    else { const uint64_t m = e->mask; for (uint64_t i = 0; i < length; ++i, next += bw) { uint64_t v; memcpy(&v, next, 8); values[i] = (v & m) + base; } }
+    return;
+  }
+  const uint64_t mask = e->mask;
+  uint64_t bits = start * (uint64_t)w;
+  if (w <= 58) {
+    for (uint64_t i = 0; i < length; ++i, bits += (uint64_t)w) {
+      uint64_t word; memcpy(&word, e->payload + (bits >> 3), 8);
+      values[i] = ((word >> (bits & 7)) & mask) + base;
+    }
+    return;
+  }
+  for (uint64_t i = 0; i < length; ++i, bits += (uint64_t)w) {
+    const uint64_t off = bits >> 3, rem = bits & 7;
+    uint64_t word; memcpy(&word, e->payload + off, 8);
+    const int overflow = w + (int)rem - 64;
+    if (overflow > 0) {
+      uint64_t next; memcpy(&next, e->payload + off + 8, 8);
+      values[i] = (((word >> rem) | (next << (w - overflow))) & mask) + base;
+    } else {
+      values[i] = ((word >> rem) & mask) + base;
+    }
+  }
+}
+/* bulkGetWithBaseline<T> (FixedBitArray.h:104-138): 8- and 4-byte outputs directly,
+ * narrow outputs through 1024-element uint32 chunks */
+static void fbw_materialize_bulk(orc_enc* e, uint32_t n, void* buffer) {
+  if (e->bit_width == 0) {  /* bufferSize is 0 bits wide: every value is the baseline */
+    switch (e->es) {
+      case 8: { uint64_t* o = (uint64_t*)buffer; for (uint32_t i = 0; i < n; ++i) o[i] = e->baseline; break; }
+      case 4: { uint32_t* o = (uint32_t*)buffer; for (uint32_t i = 0; i < n; ++i) o[i] = (uint32_t)e->baseline; break; }
+      case 2: { uint16_t* o = (uint16_t*)buffer; for (uint32_t i = 0; i < n; ++i) o[i] = (uint16_t)e->baseline; break; }
+      default: memset(buffer, (int)(uint8_t)e->baseline, n); break;
+    }
+  } else if (e->es == 8) {
+    fba_bulk64(e, e->row, n, (uint64_t*)buffer, e->baseline);
+  } else if (e->es == 4) {
+    fba_bulk32(e, e->row, n, (uint32_t*)buffer, (uint32_t)e->baseline);
+  } else {
+    uint32_t tmp[1024];
+    for (uint32_t done = 0; done < n;) {
+      const uint32_t k = n - done < 1024 ? n - done : 1024;
+      fba_bulk32(e, (uint64_t)e->row + done, k, tmp, (uint32_t)e->baseline);
+      if (e->es == 2) { uint16_t* o = (uint16_t*)buffer + done; for (uint32_t i = 0; i < k; ++i) o[i] = (uint16_t)tmp[i]; }
+      else { uint8_t* o = (uint8_t*)buffer + done; for (uint32_t i = 0; i < k; ++i) o[i] = (uint8_t)tmp[i]; }
+      done += k;
+    }
+  }
+  e->row += n;
+}
+
 static void fbw_reset(orc_enc* e) { e->row = 0; }
 static void fbw_skip(orc_enc* e, uint32_t n) { e->row += n; }
 static void fbw_materialize(orc_enc* e, uint32_t n, void* buffer) {
+  if (e->ctx->bulk) { fbw_materialize_bulk(e, n, buffer); return; }
   /* bulkGetWithBaseline<T>: value = packed bits + baseline, truncated to T
    * (FixedBitArray.h:104-138; narrow types go through a uint32 widening). */
   uint8_t* out = (uint8_t*)buffer;
@@ -850,6 +984,7 @@ void orc_destroy(orc_handle* h) {
   if (!h) return;
   ctx_release(&h->ctx); free(h);
 }
+void orc_set_bulk(orc_handle* h, int bulk) { h->ctx.bulk = bulk; }  /* FixedBitWidth through the bulk path from now on */
 uint32_t orc_row_count(const orc_handle* h) { return h->root->rows; }
 int orc_encoding_type(const orc_handle* h) { return h->root->etype; }
 int orc_data_type(const orc_handle* h) { return h->root->dtype; }
@@ -1147,10 +1282,19 @@ int orc_cd_skip(orc_stream_decoder* d, int64_t n) {
  * bitmap (ceil(rows/8) bytes, 1 = non-null, written only for Nullable roots,
  * null slots zero-filled as Encoding::materialize does).  Returns non-null
  * count or UINT32_MAX. */
+static uint32_t decode_all(const uint8_t* data, uint64_t size, int varint_rows, void* values, void* nulls, int bulk);
 uint32_t orc_decode_all(const uint8_t* data, uint64_t size, int varint_rows, void* values, void* nulls) {
+  return decode_all(data, size, varint_rows, values, nulls, 0);
+}
+/* The same with FixedBitWidth reads going through the bulk path (CPU baseline timing). */
+uint32_t orc_decode_all_fast(const uint8_t* data, uint64_t size, int varint_rows, void* values, void* nulls) {
+  return decode_all(data, size, varint_rows, values, nulls, 1);
+}
+static uint32_t decode_all(const uint8_t* data, uint64_t size, int varint_rows, void* values, void* nulls, int bulk) {
   char err[256];
   orc_handle* h = orc_create(data, size, varint_rows, err, sizeof err);
   if (!h) return UINT32_MAX;
+  h->ctx.bulk = bulk;
   uint32_t n = h->root->rows, nn = n;
   if (setjmp(h->ctx.jb)) { orc_destroy(h); return UINT32_MAX; }
   if (h->root->nullable && nulls) {

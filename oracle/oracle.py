@@ -83,6 +83,9 @@ def lib():
         L.orc_cd_skip.argtypes = [vp, i64]
         L.orc_decode_all.restype = u32
         L.orc_decode_all.argtypes = [u8p, u64, i32, vp, vp]
+        L.orc_decode_all_fast.restype = u32
+        L.orc_decode_all_fast.argtypes = [u8p, u64, i32, vp, vp]
+        L.orc_set_bulk.argtypes = [vp, i32]
         _lib = L
     return _lib
 
