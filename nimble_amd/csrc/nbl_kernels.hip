@@ -38,6 +38,18 @@ __device__ __forceinline__ uint16_t ldu16(const uint8_t* p) {
 }
 __device__ __forceinline__ uint64_t wmask(uint32_t w) { return w >= 64 ? ~0ull : ((1ull << w) - 1ull); }
 
+// Scalar load of a dword that no wave of the running launch writes (descriptor
+// tables, tile tables, scan results of an earlier launch), at a wave-uniform
+// address.  Read through the constant address space it is always a scalar load
+// (s_load, merged into wide ones), whatever stores precede it in the kernel;
+// as an ordinary global load the compiler turns it into a vector load as soon
+// as any store may precede it, and a vector load on a CU that is busy storing
+// waits behind that CU's queue.
+__device__ __forceinline__ uint32_t sload32(const uint32_t* p) {
+  typedef const uint32_t __attribute__((address_space(4))) * const_ptr;
+  return *reinterpret_cast<const_ptr>(reinterpret_cast<uintptr_t>(p));
+}
+
 template <int ES>
 struct ElemT;
 template <> struct ElemT<1> { using type = uint8_t; };
@@ -1177,8 +1189,8 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
   constexpr uint32_t TE = select_tile_rows(ES);
   constexpr uint32_t W = TE / 64;
   static_assert(TE * ES == kTileBytes && W <= kBlock, "tile geometry");
-  const uint32_t base = a.parts[pslot];
-  const uint32_t next = a.parts[pslot + 1];  // the node's total sits behind its last partial
+  const uint32_t base = sload32(a.parts + pslot);
+  const uint32_t next = sload32(a.parts + pslot + 1);  // the node's total sits behind its last partial
   uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem + kStageBytes);         // W <= 256 words
   uint32_t* s_pref = reinterpret_cast<uint32_t*>(smem + kStageBytes + 2048);  // W words
   uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + kStageBytes + 3072);
@@ -1865,13 +1877,34 @@ __device__ __forceinline__ void run_op(const KArgs& a, const NodeDesc& nd, uint3
   else if constexpr (K == K_FRAME_UNPACK) body_frame_unpack<ES>(a, nd, tile, smem);
 }
 
+// The descriptor of a tile's node, copied by value ahead of every store of the
+// body: the copy is a handful of scalar loads issued together.  Read through a
+// reference instead, each field is fetched where it is first used, and once the
+// body has stored anything (`work` holds the descriptors too, so the compiler
+// must assume they changed) those fetches are vector loads the wave waits for
+// one after the other, behind the CU's queued stores.  Copied dword by dword so
+// that the byte-sized fields (kind, width, element size) come out of scalar
+// dword loads as well -- there is no scalar byte load.
+__device__ __forceinline__ NodeDesc load_node(const NodeDesc* p) {
+  static_assert(sizeof(NodeDesc) % 4 == 0, "whole dwords");
+  typedef uint32_t __attribute__((may_alias)) word_t;
+  NodeDesc nd;
+  word_t* dst = reinterpret_cast<word_t*>(&nd);
+#pragma unroll
+  for (uint32_t i = 0; i < sizeof(NodeDesc) / 4; ++i) dst[i] = sload32(reinterpret_cast<const uint32_t*>(p) + i);
+  return nd;
+}
+
 // One kernel per operation (used when the plan is not fused: profiling, tuning).
 template <uint32_t OP>
 __device__ __forceinline__ void single_op_kernel(const KArgs& a) {
   __shared__ __align__(16) uint8_t smem[kSmemBytes];
-  const TileRef tr = a.tiles[blockIdx.x];
-  const uint32_t aux = a.tile_aux[blockIdx.x];
-  run_op<OP>(a, a.nodes[tr.node], tr.tile & kTileMask, smem, aux);
+  TileRef tr;
+  tr.node = sload32(&a.tiles[blockIdx.x].node);
+  tr.tile = sload32(&a.tiles[blockIdx.x].tile);
+  const uint32_t aux = sload32(a.tile_aux + blockIdx.x);
+  const NodeDesc nd = load_node(a.nodes + tr.node);
+  run_op<OP>(a, nd, tr.tile & kTileMask, smem, aux);
 }
 #define NBL_KERNEL_ES(name, KID) \
   template <int ES> __global__ __launch_bounds__(256) void name(KArgs a) { single_op_kernel<make_op(KID, ES)>(a); }
@@ -1904,14 +1937,38 @@ NBL_KERNEL_ES(k_frame_unpack, K_FRAME_UNPACK)
 // uniform, so the switch costs one scalar branch).  LAST only changes the
 // kernel's name, so that profiles tell the output-writing level from the
 // preparatory ones.
+// The kernel's arguments, read from the kernel-argument segment where they are
+// needed instead of through the by-value parameter: the compiler loads a
+// parameter's fields at the kernel's entry and keeps them in scalar registers
+// across the whole switch, and together with a node descriptor they do not fit
+// the 80 scalar registers of a kernel that keeps 8 workgroups per CU -- it
+// spilled hundreds of them through vector-register lanes.  KArgs is the only
+// parameter, so it starts the segment.
+typedef const KArgs __attribute__((address_space(4))) * KArgsSegment;
+__device__ __forceinline__ KArgs load_args(KArgsSegment k) {
+  KArgs a;
+  a.arena = k->arena; a.out = k->out; a.work = k->work; a.nodes = k->nodes; a.tiles = k->tiles;
+  a.tile_aux = k->tile_aux; a.parts = k->parts; a.totals = k->totals; a.status = k->status; a.n_tiles = k->n_tiles;
+  return a;
+}
+
 template <bool LAST>
-__global__ __launch_bounds__(256, 8) void k_level(KArgs a) {
+__global__ __launch_bounds__(256, 8) void k_level(KArgs) {
   __shared__ __align__(16) uint8_t smem[kSmemBytes];
-  const TileRef tr = a.tiles[blockIdx.x];
-  const uint32_t aux = a.tile_aux[blockIdx.x];
-  const NodeDesc& nd = a.nodes[tr.node];
+  const KArgsSegment ka = (KArgsSegment)__builtin_amdgcn_kernarg_segment_ptr();
+  TileRef tr;
+  tr.node = sload32(&ka->tiles[blockIdx.x].node);
+  tr.tile = sload32(&ka->tiles[blockIdx.x].tile);
+  const uint32_t aux = sload32(ka->tile_aux + blockIdx.x);
   const uint32_t tile = tr.tile & kTileMask;
-#define NBL_OP(KID, ES) case make_op(KID, ES): run_op<make_op(KID, ES)>(a, nd, tile, smem, aux); break;
+  // every operation copies the arguments and its node's descriptor itself, so
+  // only what that operation reads is live in it
+#define NBL_OP(KID, ES)                                      \
+  case make_op(KID, ES): {                                   \
+    const KArgs a = load_args(ka);                           \
+    const NodeDesc nd = load_node(a.nodes + tr.node);        \
+    run_op<make_op(KID, ES)>(a, nd, tile, smem, aux);        \
+  } break;
 #define NBL_OP_ALL_ES(KID) NBL_OP(KID, 1) NBL_OP(KID, 2) NBL_OP(KID, 4) NBL_OP(KID, 8)
   switch (tr.tile >> kOpShift) {
     NBL_OP_ALL_ES(K_MATERIALIZE)

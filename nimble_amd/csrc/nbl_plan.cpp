@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -1161,8 +1162,11 @@ nbl_status nbl_profile_create(const nbl_plan* p, uint32_t max_steps, nbl_profile
   nbl_profile* pr = new nbl_profile();
   pr->n_launches = (uint32_t)p->launches.size();
   pr->max_steps = max_steps;
+  // NBL_PROFILE_UNGROUPED=1 (tuning aid): every launch is a group of its own
+  const char* ungrouped = getenv("NBL_PROFILE_UNGROUPED");
+  const bool split = ungrouped && ungrouped[0] == '1';
   for (size_t l = 0; l < p->launches.size(); ++l) {
-    if (l == 0 || p->launches[l].name != p->launches[l - 1].name) { pr->group_size.push_back(0); }
+    if (l == 0 || split || p->launches[l].name != p->launches[l - 1].name) { pr->group_size.push_back(0); }
     pr->group_of.push_back((uint32_t)pr->group_size.size() - 1);
     ++pr->group_size.back();
   }

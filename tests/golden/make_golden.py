@@ -145,8 +145,12 @@ def varint_enc(vals, dt, base=None, vr=False):
 CASES = []
 
 
-def add(name, enc, dt, expected, nulls=None, vr=False, source=""):
-    c = {"name": name, "data_type": dt, "varint_rows": vr, "hex": enc.hex(), "source": source}
+def add(name, enc, dt, expected, nulls=None, vr=False, source="", origin="self-assembled"):
+    """origin: "reference-held" when the bytes are exactly what one of the reference's
+    own tests assembles field by field (the citing file:line is in `source`);
+    "self-assembled" when this script put them together from the documented layout."""
+    assert origin in ("reference-held", "self-assembled")
+    c = {"name": name, "data_type": dt, "varint_rows": vr, "hex": enc.hex(), "source": source, "origin": origin}
     if dt == STR:
         c["expected_strings_hex"] = [s.hex() for s in expected]
     elif dt == BOOL:
@@ -162,11 +166,14 @@ def add(name, enc, dt, expected, nulls=None, vr=False, source=""):
 def main():
     r53 = list(range(53))
     add("fbw_u32_0to52_byte_rounded", fbw(r53, U32, 8), U32, r53,
-        source="FixedBitWidthEncodingTest.cpp:76-103,190-199 (encodeByteRounded)")
+        source="encodings/tests/FixedBitWidthEncodingTest.cpp:76-103 (encodeByteRounded: prefix, compression byte, "
+               "u32 baseline 0, bit-width byte 8, FixedBitArray payload of bufferSize bytes), input {0..52} of :140-188",
+        origin="reference-held")
     add("fbw_u32_0to52_exact_6bits", fbw(r53, U32, 6), U32, r53,
         source="FixedBitWidthEncodingTest.cpp:140-188 (bit-width byte == 6 with exact bits)")
     add("fbw_u32_0to52_varint_prefix", fbw(r53, U32, 8, vr=True), U32, r53, vr=True,
-        source="FixedBitWidthEncodingTest.cpp:118 (FBWTestConfig<true>)")
+        source="encodings/tests/FixedBitWidthEncodingTest.cpp:76-103 with useVarintRowCount (FBWTestConfig<true>, :118)",
+        origin="reference-held")
     r10 = list(range(10))
     add("fbw_u32_0to9", fbw(r10, U32, 8), U32, r10, source="FixedBitWidthEncodingTest.cpp:122-138")
     add("fbw_u32_single_42", fbw([42], U32, 8, base=42), U32, [42], source="FixedBitWidthEncodingTest.cpp:332-388")
@@ -258,10 +265,71 @@ def main():
     add("nullable_mainly_constant_dictionary",
         nullable(mainly_constant(nn2, I32, 1, dictionary([2, 3], I32)), mask[:9], I32), I32, full2, nulls=mask[:9],
         source="encodings/tests/EncodingTest.cpp:1295-1340")
-    out = {"format": 1,
-           "note": "hand-assembled; regenerate with tests/golden/make_golden.py",
+    # ---- streams the reference's own tests assemble byte by byte --------------------
+    # tools/tests/EncodingUtilitiesTest.cpp:42-70 buildTrivialUint32Stream: prefix | Uncompressed | raw u32
+    for vals, where in (([10, 20, 30], ":194-201"), ([1, 2, 3], ":213-243"), ([10, 20], ":291-313 (encoded size 15)"),
+                        ([0, 64], ":425-431 (BlockBitPacking baselines)"), ([0, 5], ":413 (PFOR exception positions)")):
+        add("ref_trivial_u32_" + "_".join(map(str, vals)), trivial(vals, U32), U32, vals,
+            source="tools/tests/EncodingUtilitiesTest.cpp:42-70 buildTrivialUint32Stream, used at " + where,
+            origin="reference-held")
+    assert len(trivial([10, 20], U32)) == 15  # EncodingUtilitiesTest.cpp:311-312
+    add("ref_trivial_u32_varint_rows", trivial([10, 20, 30], U32, vr=True), U32, [10, 20, 30], vr=True,
+        source="tools/tests/EncodingUtilitiesTest.cpp:49-70 buildTrivialUint32Stream(values, useVarintRowCount = true)",
+        origin="reference-held")
+    # tools/tests/EncodingUtilitiesTest.cpp:72-90 buildConstantUint32Stream: prefix | u32 value
+    for value, rows, where in ((42, 100, ":203-208"), (99, 50, ":245-274")):
+        add(f"ref_constant_u32_{value}x{rows}", constant(value, rows, U32), U32, [value] * rows,
+            source="tools/tests/EncodingUtilitiesTest.cpp:72-90 buildConstantUint32Stream, used at " + where,
+            origin="reference-held")
+    # BlockBitPacking header with its three varint-sized metadata children and NO packed data
+    # (tools/tests/EncodingUtilitiesTest.cpp:130-178 buildBlockBitPackingUint32Stream, children of :425-431):
+    # the reference's traverseEncodings visits Baselines, BitWidths, DataOffsets in this order (:432-455)
+    kids = [trivial([0, 64], U32), trivial([4, 5], U32), trivial([0, 32], U32)]
+    bbp = prefix(15, U32, 100) + b"\x00" + varint(64) + varint(2)
+    for k in kids:
+        bbp += varint(len(k)) + k
+    bbp += varint(64)
+    headers = [{
+        "name": "ref_block_bit_packing_header", "origin": "reference-held", "hex": bbp.hex(),
+        "source": "tools/tests/EncodingUtilitiesTest.cpp:130-178,425-455",
+        "encoding_type": 15, "data_type": U32, "rows": 100, "block_size": 64, "blocks": 2, "first_block_rows": 64,
+        "children_hex": [k.hex() for k in kids], "children_names": ["Baselines", "BitWidths", "DataOffsets"],
+    }]
+    # encoding prefixes (encodings/tests/EncodingPrefixTest.cpp:42-83): EncodingPrefix::serialize output
+    prefixes = [
+        {"origin": "reference-held", "source": "encodings/tests/EncodingPrefixTest.cpp:42-54", "encoding_type": 8,
+         "data_type": I64, "rows": 123, "varint_rows": False, "hex": prefix(8, I64, 123).hex()},
+        {"origin": "reference-held", "source": "encodings/tests/EncodingPrefixTest.cpp:56-68", "encoding_type": TRIVIAL,
+         "data_type": U32, "rows": 123, "varint_rows": False, "hex": prefix(TRIVIAL, U32, 123).hex()},
+        {"origin": "reference-held", "source": "encodings/tests/EncodingPrefixTest.cpp:70-83", "encoding_type": RLE,
+         "data_type": STR, "rows": 1000000, "varint_rows": True, "hex": prefix(RLE, STR, 1000000, vr=True).hex()},
+    ]
+    # chunk headers (common/tests/ChunkHeaderTest.cpp:23-52): u32 length | u8 CompressionType (Zstd = 1)
+    chunk_headers = [
+        {"origin": "reference-held", "source": "common/tests/ChunkHeaderTest.cpp:28-39", "length": 1234, "compression": 1,
+         "hex": (struct.pack("<I", 1234) + b"\x01").hex()},
+        {"origin": "reference-held", "source": "common/tests/ChunkHeaderTest.cpp:41-50", "length": 42, "compression": 0,
+         "hex": (struct.pack("<I", 42) + b"\x00").hex()},
+        {"origin": "reference-held", "source": "common/tests/ChunkHeaderTest.cpp:52-62", "length": 100000, "compression": 1,
+         "hex": (struct.pack("<I", 100000) + b"\x01").hex()},
+    ]
+    # varint sizes at the boundaries (common/tests/VarintTests.cpp:64-76,95-103)
+    varint_sizes = [{"value": v, "size": n} for v, n in
+                    ((0, 1), (1, 1), (127, 1), (128, 2), (16383, 2), (16384, 3), (2097151, 3), (2097152, 4),
+                     (268435455, 4), (268435456, 5), (2**32 - 1, 5), (2**64 - 1, 10))]
+    for e in varint_sizes:
+        assert len(varint(e["value"])) == e["size"]
+    out = {"format": 2,
+           "note": "hand-assembled; regenerate with tests/golden/make_golden.py.  origin = reference-held: the bytes are "
+                   "what one of the reference's own tests assembles field by field; self-assembled: put together here "
+                   "from the layout the reference documents",
            "chunk_header_size": 5,
-           "cases": CASES}
+           "cases": CASES,
+           "headers": headers,
+           "prefixes": prefixes,
+           "chunk_headers": chunk_headers,
+           "varint_sizes": {"origin": "reference-held", "source": "common/tests/VarintTests.cpp:64-76,95-103",
+                            "entries": varint_sizes}}
     with open(os.path.join(HERE, "golden_v1.json"), "w") as f:
         json.dump(out, f, indent=0)
     print(f"wrote {len(CASES)} cases")
