@@ -88,6 +88,12 @@ enum NodeFlags : uint32_t {
   NF_SPARSE_VALUE = 1u << 2, // SparseBool: listed positions are 1
   NF_FIRST_TRUE = 1u << 3,   // RLE<bool>: first run is true
   NF_DICT_VALUES = 1u << 5,  // K_SELECT_SCATTER: c1 holds dictionary indices (uint32), c0 the alphabet; gather inline
+  NF_RLE_VALUES = 1u << 7,     // K_SELECT_SCATTER: the values child is an RLE expanded here as well: c0 = its run ends
+                               // (uint32 array in work, c0.rows = its row count; first_run[] behind it), c1 = its run
+                               // values, total_idx2 = its slot in the node-totals array
+  NF_NESTED_SELECT = 1u << 6,  // K_SELECT_SCATTER: the values child is a MainlyConstant resolved here as well: c0 = its
+                               // isCommon bitmap (other values where the bit is 0), c1 = its other values, aux3 = its
+                               // common value, part_base2 / total_idx2 = its scanned rank partials and total
   NF_FRAME_BITS = 1u << 4,   // K_FRAME_UNPACK: FOR (u64 bit offsets, no raw marker) instead of
                              // BlockBitPacking (u32 byte offsets, width 255 = raw block)
 };
@@ -121,6 +127,9 @@ struct NodeDesc {
   uint32_t n_parts;   // number of scan tiles
   uint32_t total_idx; // slot in the node-totals array
   uint32_t pad;
+  uint64_t aux3;       // NF_NESTED_SELECT: fill value of the inner selection (its common value)
+  uint32_t part_base2; // NF_NESTED_SELECT: first slot of the inner node's rank partials
+  uint32_t total_idx2; // NF_NESTED_SELECT: the inner node's slot in the node-totals array
 };
 
 struct TileRef {

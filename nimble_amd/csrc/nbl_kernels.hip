@@ -127,18 +127,27 @@ __device__ __forceinline__ uint32_t col_bit(const ColRef& c, const KArgs& a, uin
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t wave_id() { return threadIdx.x >> 6; }
 
+// Inclusive scan over the 64 lanes of a wave with data-parallel-primitive moves:
+// four shifts inside the 16-lane rows, then the last lane of row 0 / 2 is added
+// to row 1 / 3 and lane 31 to the upper half.  Six dependent vector adds; the
+// same scan through cross-lane shuffles (LDS permutes) is six LDS round trips,
+// an order of magnitude more latency on what is the serial part of every tile
+// that has data-dependent positions.  Lanes without a source add 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_add(uint32_t v) {
+  return v + (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint32_t t = __shfl_up(v, d, 64);
-    if ((int)lane_id() >= d) v += t;
-  }
+  v = dpp_add<0x111, 0xF>(v);  // row_shr:1
+  v = dpp_add<0x112, 0xF>(v);  // row_shr:2
+  v = dpp_add<0x114, 0xF>(v);  // row_shr:4
+  v = dpp_add<0x118, 0xF>(v);  // row_shr:8
+  v = dpp_add<0x142, 0xA>(v);  // row_bcast:15 into rows 1 and 3
+  v = dpp_add<0x143, 0xC>(v);  // row_bcast:31 into rows 2 and 3
   return v;
 }
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
-#pragma unroll
-  for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
+  return (uint32_t)__builtin_amdgcn_readlane((int)wave_incl_scan(v), 63);
 }
 // Exclusive scan over the 256 threads of the block; `tmp` holds >= 4 words.
 // Returns the exclusive prefix of the caller, block total in `total`.
@@ -848,7 +857,7 @@ __device__ __forceinline__ void body_rle_ends(const KArgs& a, const NodeDesc& nd
     v[j] = s;
   }
   uint32_t total;
-  const uint32_t ex = block_excl_scan(s, tmp, total) + a.parts[nd.part_base + tile];
+  const uint32_t ex = block_excl_scan(s, tmp, total) + sload32(a.parts + nd.part_base + tile);
   uint32_t* ends = reinterpret_cast<uint32_t*>(a.work + nd.aux_off);
   if (e0 + 8 <= n) {
     *reinterpret_cast<u32x4*>(ends + e0) = make_u32x4(v[0] + ex, v[1] + ex, v[2] + ex, v[3] + ex);
@@ -922,7 +931,7 @@ __device__ __forceinline__ void body_rle_expand(const KArgs& a, const NodeDesc& 
   const uint64_t p1 = p0 + TE < rows ? p0 + TE : rows;
   T* dst = reinterpret_cast<T*>(self_ptr(nd, a));
   const uint32_t* ends = reinterpret_cast<const uint32_t*>(a.work + nd.aux_off);
-  if (tile == 0 && threadIdx.x == 0 && a.totals[nd.total_idx] != nd.rows) atomicOr(a.status, ST_RLE_SUM_MISMATCH);
+  if (tile == 0 && threadIdx.x == 0 && sload32(a.totals + nd.total_idx) != nd.rows) atomicOr(a.status, ST_RLE_SUM_MISMATCH);
   if (R == 0) {  // malformed: rows without runs
     for (uint32_t it = 0; it < 4; ++it) {
       const uint64_t e0 = p0 + (uint64_t)(it * kBlock + threadIdx.x) * V;
@@ -932,7 +941,8 @@ __device__ __forceinline__ void body_rle_expand(const KArgs& a, const NodeDesc& 
     }
     return;
   }
-  const bool zero_runs = a.totals[nd.total_idx + 1] != 0;
+  // totals, first_run and the tile partials were written by an EARLIER launch: scalar loads
+  const bool zero_runs = sload32(a.totals + nd.total_idx + 1) != 0;
   uint32_t k0, k1;
   uint32_t e_first = 0;  // run end this thread marks first (loaded before the barrier below)
   if (zero_runs) {
@@ -947,8 +957,8 @@ __device__ __forceinline__ void body_rle_expand(const KArgs& a, const NodeDesc& 
     // thread reads the two entries itself (one address: a scalar load), so the
     // first run ends are in flight before the barrier.
     const uint32_t* first_run = rle_first_run(a, nd);
-    const uint32_t f0 = first_run[tile];
-    const uint32_t f1 = p0 + TE < rows ? first_run[tile + 1] : R - 1;
+    const uint32_t f0 = sload32(first_run + tile);
+    const uint32_t f1 = p0 + TE < rows ? sload32(first_run + tile + 1) : R - 1;
     const uint32_t c0 = f0 < R ? f0 : R - 1;
     uint32_t c1 = f1 < R ? f1 : R - 1;
     if (c1 < c0) c1 = c0;
@@ -1032,18 +1042,18 @@ __device__ __forceinline__ void body_rle_expand_bool(const KArgs& a, const NodeD
   const uint32_t* ends = reinterpret_cast<const uint32_t*>(a.work + nd.aux_off);
   const uint64_t firstmask = (nd.flags & NF_FIRST_TRUE) ? ~0ull : 0ull;
   const uint64_t w = (uint64_t)tile * W + threadIdx.x;  // output word of this thread
-  if (tile == 0 && threadIdx.x == 0 && a.totals[nd.total_idx] != nd.rows) atomicOr(a.status, ST_RLE_SUM_MISMATCH);
+  if (tile == 0 && threadIdx.x == 0 && sload32(a.totals + nd.total_idx) != nd.rows) atomicOr(a.status, ST_RLE_SUM_MISMATCH);
   if (R == 0) {
     if (w * 64 < rows) dst[w] = 0;
     return;
   }
-  const bool slow = a.totals[nd.total_idx + 1] != 0;
+  const bool slow = sload32(a.totals + nd.total_idx + 1) != 0;
   if (slow) {
     find_run_range(ends, R, p0, p1, s_k);
   } else if (threadIdx.x == 0) {
     const uint32_t* first_run = rle_first_run(a, nd);
-    const uint32_t f0 = first_run[tile];
-    const uint32_t f1 = p0 + kBitTileRows < rows ? first_run[tile + 1] : R - 1;
+    const uint32_t f0 = sload32(first_run + tile);
+    const uint32_t f1 = p0 + kBitTileRows < rows ? sload32(first_run + tile + 1) : R - 1;
     const uint32_t c0 = f0 < R ? f0 : R - 1;
     const uint32_t c1 = f1 < R ? f1 : R - 1;
     s_k[0] = c0; s_k[1] = c1 < c0 ? c0 : c1;
@@ -1172,6 +1182,260 @@ __device__ __forceinline__ void tile_rank_scan(uint64_t word, uint64_t* s_bits, 
   }
 }
 
+// Rank scatter whose values child is an RLE (Nullable{RLE{..}}): the runs are
+// expanded here, so the expanded column is never written out and read back.
+// The tile's ranks [base, base + n) are rows of the RLE node; the runs that
+// hold them lie between first_run[] of the RLE tile holding `base` and
+// first_run[] of the tile behind the one holding the last rank -- both known
+// from scalar loads, so run ends and run values are fetched together.  Run
+// boundaries inside the tile's ranks become a bitmap over ranks (as in
+// body_rle_expand over rows) and a row's run is a popcount prefix.
+template <int ES, typename RD>
+__device__ __forceinline__ void select_rle(const KArgs& a, const NodeDesc& nd, const RD& rd, uint8_t* smem, uint64_t word,
+                                           uint32_t base, uint32_t n, uint32_t tile_rows,
+                                           typename ElemT<ES>::type* dst, typename ElemT<ES>::type fill) {
+  using T = typename ElemT<ES>::type;
+  constexpr uint32_t V = 16 / ES;
+  constexpr uint32_t TE = select_tile_rows(ES);
+  constexpr uint32_t W = TE / 64;
+  static_assert(W <= 64 && 2 * W <= 256, "outer words, then the run-boundary words, share the bitmap area");
+  uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem + kStageBytes);
+  uint32_t* s_pref = reinterpret_cast<uint32_t*>(smem + kStageBytes + 2048);
+  uint32_t* s_cnt = reinterpret_cast<uint32_t*>(smem + kStageBytes + 3072) + 8;  // runs of the fetched range ending at or before `base`
+  const uint32_t R = nd.c1.rows;                 // runs (> 0: the planner fuses non-empty RLE nodes only)
+  const uint32_t rows_r = nd.c0.rows;            // rows of the RLE node
+  const uint32_t* ends = reinterpret_cast<const uint32_t*>(a.work + nd.c0.off);
+  const uint32_t* first_run = ends + (((uint64_t)R + 3) & ~3ull);
+  const uint32_t n_rtiles = (rows_r + TE - 1) / TE;
+  const uint32_t t0 = base / TE, t1 = (base + n - 1) / TE;   // RLE tiles holding the first and the last rank
+  uint32_t kf = sload32(first_run + t0);
+  uint32_t kl = t1 + 1 < n_rtiles ? sload32(first_run + t1 + 1) : R - 1;
+  kf = kf < R ? kf : R - 1;                                  // payload data: clamped, never followed
+  kl = kl < R ? kl : R - 1;
+  kl = kl < kf ? kf : kl;
+  const uint32_t nsup = kl - kf + 1;                         // runs fetched
+  const bool zero_runs = sload32(a.totals + nd.total_idx2 + 1) != 0;
+  const bool fast = !zero_runs && rd.fits(nsup) && nsup <= 4 * kBlock;
+  if (threadIdx.x < 64) {                                    // the outer ranks: wave 0, as in the plain scatter
+    const uint32_t c = (uint32_t)__popcll(word);
+    const uint32_t incl = wave_incl_scan(c);
+    if (threadIdx.x < W) { s_bits[threadIdx.x] = word; s_pref[threadIdx.x] = incl - c; }
+  }
+  if (!fast) {
+    // zero-length runs, or more runs than the stage holds: every selected row finds its run by binary search
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t q = threadIdx.x; q < tile_rows; q += kBlock) {
+      const uint64_t wd = s_bits[q >> 6];
+      T v = fill;
+      if ((wd >> (q & 63)) & 1ull) {
+        uint32_t r = base + s_pref[q >> 6] + (uint32_t)__popcll(wd & ((1ull << (q & 63)) - 1ull));
+        r = r < base + n - 1 ? r : base + n - 1;
+        v = rd.get(run_of_row(ends, kf, kl, r));
+      }
+      dst[q] = v;
+    }
+    return;
+  }
+  // run ends of the fetched range (up to four per thread) and the run values, all in flight together
+  uint32_t e[4];
+#pragma unroll
+  for (uint32_t u = 0; u < 4; ++u) {
+    const uint32_t j = kf + u * kBlock + threadIdx.x;
+    e[u] = j < kl ? ends[j] : 0xFFFFFFFFu;                   // run kl's end is not needed: nothing of the tile lies behind it
+  }
+  StageRegs<5> regs;
+  const uint32_t bit0 = rd.stage_begin(kf, nsup, regs);
+  if (threadIdx.x < W) s_bits[W + threadIdx.x] = 0;
+  if (threadIdx.x == 0) *s_cnt = 0;
+  __syncthreads();
+  uint32_t* bits32 = reinterpret_cast<uint32_t*>(s_bits + W);
+  uint32_t before = 0;
+#pragma unroll
+  for (uint32_t u = 0; u < 4; ++u) {
+    if (e[u] <= base) ++before;
+    else if (e[u] < base + n) atomicOr(&bits32[(e[u] - base) >> 5], 1u << ((e[u] - base) & 31));
+  }
+  before = wave_sum(before);
+  if (lane_id() == 0 && before) atomicAdd(s_cnt, before);
+  const auto vals = rd.stage_end(regs, bit0, smem);
+  __syncthreads();
+  if (threadIdx.x < 64) {                                    // prefix over the boundary words: one wave
+    const uint32_t c = threadIdx.x < W ? (uint32_t)__popcll(s_bits[W + threadIdx.x]) : 0u;
+    const uint32_t incl = wave_incl_scan(c);
+    if (threadIdx.x < W) s_pref[W + threadIdx.x] = incl - c;
+  }
+  __syncthreads();
+  const uint32_t k0 = *s_cnt;                                // run of rank `base`, relative to kf
+  const uint32_t lastq = n - 1, lastrun = nsup - 1;
+#pragma unroll
+  for (uint32_t it = 0; it < 4; ++it) {
+    const uint32_t q0 = (it * kBlock + threadIdx.x) * V;
+    if (q0 >= tile_rows) break;
+    const uint64_t wd = s_bits[q0 >> 6];
+    const uint32_t b = q0 & 63;
+    uint32_t q = s_pref[q0 >> 6] + (uint32_t)__popcll(wd & ((1ull << b) - 1ull));  // rank relative to base
+    const uint32_t bits = (uint32_t)(wd >> b);
+    Vec16<ES> o;
+    if ((bits & ((1u << V) - 1u)) == 0) {
+#pragma unroll
+      for (uint32_t j = 0; j < V; ++j) o.v[j] = fill;
+    } else {
+      o.q = make_u32x4(0, 0, 0, 0);
+#pragma unroll
+      for (uint32_t j = 0; j < V; ++j) {
+        const uint32_t qc = q < lastq ? q : lastq;
+        const uint64_t bw = s_bits[W + (qc >> 6)];
+        uint32_t run = k0 + s_pref[W + (qc >> 6)] + (uint32_t)__popcll(bw & ((2ull << (qc & 63)) - 1ull));
+        run = run < lastrun ? run : lastrun;
+        const T v = vals.at(run);
+        vec_set<ES>(o, j, ((bits >> j) & 1u) ? v : fill);
+        q += (bits >> j) & 1u;
+      }
+    }
+    store_vec<ES>(dst, q0, tile_rows, o);
+  }
+}
+
+// Rank scatter whose values child is a MainlyConstant (Nullable{MainlyConstant{..}},
+// the usual shape of a sparse feature column): both selections are resolved in
+// one pass, so the inner column is never written out and read back.
+//   row p is selected by the outer bitmap -> outer rank r1 = a row of the inner node
+//   inner bit of r1 set (after inversion: "not common") -> inner rank r2 -> others[r2]
+//   otherwise the inner fill (the common value); rows the outer leaves out take `fill`.
+// The tile's outer ranks are [base, base + n).  Inner ranks come from the inner
+// node's own scanned partials (one per TE inner rows): the partial of the inner
+// tile holding `base` plus a popcount prefix over the inner bitmap words from
+// that tile's start, kept in LDS behind the outer words.  The other values the
+// tile can ask for lie between two of those partials, known before any bitmap
+// word arrives, so they are staged in LDS like the values of a plain scatter.
+template <int ES, typename RD>
+__device__ __forceinline__ void select_nested(const KArgs& a, const NodeDesc& nd, const RD& rd, uint8_t* smem, uint64_t word,
+                                              uint32_t base, uint32_t n, uint32_t tile_rows,
+                                              typename ElemT<ES>::type* dst, typename ElemT<ES>::type fill) {
+  using T = typename ElemT<ES>::type;
+  constexpr uint32_t V = 16 / ES;
+  constexpr uint32_t TE = select_tile_rows(ES);
+  constexpr uint32_t W = TE / 64;
+  static_assert(W <= 64 && 3 * W <= 256, "outer words, then up to two inner tiles of words, share the bitmap area");
+  uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem + kStageBytes);
+  uint32_t* s_pref = reinterpret_cast<uint32_t*>(smem + kStageBytes + 2048);
+  const T fill2 = (T)nd.aux3;
+  const uint32_t rows1 = nd.c0.rows;            // rows of the inner node (>= base + n, by the caller's clamp)
+  const uint32_t nothers = nd.c1.rows;
+  // inner tiles j0..j1 hold the outer ranks of this tile (n <= TE: at most two of them)
+  const uint32_t j0 = base / TE, j1 = (base + n - 1) / TE;
+  uint32_t ob = sload32(a.parts + nd.part_base2 + j0);      // inner rank at inner row j0 * TE
+  uint32_t oe = sload32(a.parts + nd.part_base2 + j1 + 1);  // inner rank behind inner tile j1
+  ob = ob < nothers ? ob : nothers;                         // scan results of damaged input are clamped, never followed
+  oe = oe < nothers ? oe : nothers;
+  oe = oe < ob ? ob : oe;
+  const uint32_t cnt2 = oe - ob;
+  const bool staged = rd.fits(cnt2);
+  const uint32_t w0 = j0 * W;                                // first inner word needed
+  const uint32_t nw = (base + n - 1) / 64 - w0 + 1;          // <= 2 W
+  const bool inv2 = true;                                    // MainlyConstant: other values where isCommon is 0
+  // wave 1 fetches and scans the inner words (lane l: words l and l + 64) while wave 0 scans the outer ones
+  uint64_t iw0 = 0, iw1 = 0;
+  const uint32_t l = threadIdx.x - 64;
+  if (threadIdx.x >= 64 && threadIdx.x < 128) {
+    if (l < nw) iw0 = bits_word_masked(nd.c0, a, w0 + l, inv2);
+    if (l + 64 < nw) iw1 = bits_word_masked(nd.c0, a, w0 + l + 64, inv2);
+  }
+  StageRegs<5> regs;
+  regs.nvec = 0;
+  uint32_t bit0 = 0;
+  if (staged && cnt2) bit0 = rd.stage_begin(ob, cnt2, regs);
+  if (threadIdx.x < 64) {
+    const uint32_t c = (uint32_t)__popcll(word);
+    const uint32_t incl = wave_incl_scan(c);
+    if (threadIdx.x < W) { s_bits[threadIdx.x] = word; s_pref[threadIdx.x] = incl - c; }
+  } else if (threadIdx.x < 128) {
+    const uint32_t c0 = (uint32_t)__popcll(iw0), c1 = (uint32_t)__popcll(iw1);
+    const uint32_t i0 = wave_incl_scan(c0);
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)i0, 63);
+    const uint32_t i1 = wave_incl_scan(c1);
+    if (l < nw) { s_bits[W + l] = iw0; s_pref[W + l] = ob + i0 - c0; }
+    if (l + 64 < nw) { s_bits[W + 64 + l] = iw1; s_pref[W + 64 + l] = ob + t0 + i1 - c1; }
+  }
+  const auto vals = rd.stage_end(regs, bit0, smem);  // regs.nvec == 0 when nothing was staged
+  __syncthreads();
+  const uint32_t last1 = base + n - 1;                // last inner row this tile may ask for (< rows1)
+  const uint32_t last2 = nothers ? nothers - 1 : 0;
+  const uint32_t* ib32 = reinterpret_cast<const uint32_t*>(s_bits + W);  // the inner words as dwords
+  if (!staged) {
+    // more other values than the stage holds (a dense inner selection): row by row from global memory
+#pragma unroll 1
+    for (uint32_t q = threadIdx.x; q < tile_rows; q += kBlock) {
+      const uint64_t wd = s_bits[q >> 6];
+      T v = fill;
+      if ((wd >> (q & 63)) & 1ull) {
+        uint32_t x = base + s_pref[q >> 6] + (uint32_t)__popcll(wd & ((1ull << (q & 63)) - 1ull));
+        x = x < last1 ? x : last1;
+        const uint32_t wi = W + (x >> 6) - w0;
+        const uint64_t wd2 = s_bits[wi];
+        v = fill2;
+        if (((wd2 >> (x & 63)) & 1ull) && nothers) {
+          const uint32_t r2 = s_pref[wi] + (uint32_t)__popcll(wd2 & ((1ull << (x & 63)) - 1ull));
+          v = rd.get(r2 < last2 ? r2 : last2);
+        }
+      }
+      dst[q] = v;
+    }
+    return;
+  }
+  // One 16-byte vector of rows at a time: its selected rows are consecutive
+  // inner rows x, x + 1, ..., so their inner bits are one short window of the
+  // inner bitmap.  Mostly that window is empty (the common value everywhere)
+  // and the vector needs no rank at all.
+#pragma unroll
+  for (uint32_t it = 0; it < 4; ++it) {
+    const uint32_t q0 = (it * kBlock + threadIdx.x) * V;
+    if (q0 >= tile_rows) break;
+    const uint64_t wd = s_bits[q0 >> 6];
+    const uint32_t b = q0 & 63;
+    const uint32_t sel = (uint32_t)(wd >> b) & ((1u << V) - 1u);  // outer bits of the V rows
+    Vec16<ES> o;
+    if (sel == 0) {
+#pragma unroll
+      for (uint32_t j = 0; j < V; ++j) o.v[j] = fill;
+    } else {
+      uint32_t x = base + s_pref[q0 >> 6] + (uint32_t)__popcll(wd & ((1ull << b) - 1ull));  // inner row of the first selected row
+      x = x < last1 ? x : last1;
+      const uint32_t xr = x - w0 * 64;                           // relative to the first staged inner word
+      const uint32_t d = xr >> 5;
+      uint32_t ib = __builtin_amdgcn_alignbit(ib32[d + 1], ib32[d], xr & 31u);  // inner bits of rows x, x + 1, ...
+      ib &= (1u << (uint32_t)__popc(sel)) - 1u;
+      o.q = make_u32x4(0, 0, 0, 0);
+      if (ib == 0) {
+#pragma unroll
+        for (uint32_t j = 0; j < V; ++j) vec_set<ES>(o, j, ((sel >> j) & 1u) ? fill2 : fill);
+      } else {
+        const uint64_t wd2 = s_bits[W + (xr >> 6)];
+        uint32_t r2 = s_pref[W + (xr >> 6)] + (uint32_t)__popcll(wd2 & ((1ull << (xr & 63)) - 1ull));  // inner rank at row x
+#pragma unroll
+        for (uint32_t j = 0; j < V; ++j) {
+          T v = fill;
+          if ((sel >> j) & 1u) {
+            v = fill2;
+            if (ib & 1u) {
+              uint32_t rc = r2 < last2 ? r2 : last2;
+              rc = rc < ob ? ob : rc;
+              rc = rc < oe ? rc : (oe ? oe - 1 : 0);
+              v = cnt2 ? vals.at(rc - ob) : (T)0;
+              ++r2;
+            }
+            ib >>= 1;
+          }
+          vec_set<ES>(o, j, v);
+        }
+      }
+    }
+    store_vec<ES>(dst, q0, tile_rows, o);
+  }
+  (void)rows1;
+}
+
 // NullableEncoding::materialize (encodings/NullableEncoding.h:207-236): row i
 // takes values[rank(i)] when its bit is set, physicalType() otherwise; and
 // MainlyConstantEncoding::materialize (encodings/MainlyConstantEncoding.h:208-253):
@@ -1199,8 +1463,18 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
   const uint32_t tile_rows = rows - p0 < TE ? (uint32_t)(rows - p0) : TE;
   const bool invert = (nd.flags & NF_INVERT_SEL) != 0;
   T* dst = reinterpret_cast<T*>(self_ptr(nd, a)) + p0;
-  const uint32_t nvals = nd.c1.rows;
-  if (tile == 0 && threadIdx.x == 0 && a.totals[nd.total_idx] != nvals) atomicOr(a.status, ST_SELECT_COUNT);
+  bool nested = false, runs = false;
+  if constexpr (ES >= 4) {  // the planner fuses 4- and 8-byte rows only
+    nested = (nd.flags & NF_NESTED_SELECT) != 0;
+    runs = (nd.flags & NF_RLE_VALUES) != 0;
+  }
+  const uint32_t nvals = (nested || runs) ? nd.c0.rows : nd.c1.rows;  // rows of the values child
+  if (tile == 0 && threadIdx.x == 0) {
+    bool bad = sload32(a.totals + nd.total_idx) != nvals;
+    if (nested) bad |= sload32(a.totals + nd.total_idx2) != nd.c1.rows;
+    if (bad) atomicOr(a.status, ST_SELECT_COUNT);
+    if (runs && sload32(a.totals + nd.total_idx2) != nvals) atomicOr(a.status, ST_RLE_SUM_MISMATCH);
+  }
   // The tile's selected rows take the consecutive ranks [base, next): both come
   // from the scanned partials, so the values can be fetched without waiting for
   // the bitmap.  Counts that disagree with the values child (corrupt input) are
@@ -1229,6 +1503,16 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
     return;
   }
   const uint32_t last = n - 1;
+  if constexpr (ES >= 4) if (runs) {
+    write_nulls();
+    with_reader<ES>(nd.c1, a, [&](auto rd) { select_rle<ES>(a, nd, rd, smem, word, base, n, tile_rows, dst, fill); });
+    return;
+  }
+  if constexpr (ES >= 4) if (nested) {
+    write_nulls();
+    with_reader<ES>(nd.c1, a, [&](auto rd) { select_nested<ES>(a, nd, rd, smem, word, base, n, tile_rows, dst, fill); });
+    return;
+  }
   if constexpr (ES >= 4) if (nd.flags & NF_DICT_VALUES) {  // the planner fuses 4- and 8-byte rows only
     // The values child is a Dictionary whose gather is done here: c1 = its uint32
     // indices (staged like any values), c0 = its alphabet as a plain element
@@ -1330,7 +1614,7 @@ __device__ __forceinline__ void body_select_bits(const KArgs& a, const NodeDesc&
   const uint64_t rows = nd.rows;
   const uint32_t nvals = nd.c1.rows;
   uint64_t* dst = reinterpret_cast<uint64_t*>(a.work + nd.self.off);
-  if (tile == 0 && threadIdx.x == 0 && a.totals[nd.total_idx] != nvals) atomicOr(a.status, ST_SELECT_COUNT);
+  if (tile == 0 && threadIdx.x == 0 && sload32(a.totals + nd.total_idx) != nvals) atomicOr(a.status, ST_SELECT_COUNT);
   const uint64_t w = (uint64_t)tile * W + threadIdx.x;
   uint64_t word = 0;
   if (w * 64 < rows) {
@@ -1341,7 +1625,7 @@ __device__ __forceinline__ void body_select_bits(const KArgs& a, const NodeDesc&
   const uint32_t ex = block_excl_scan((uint32_t)__popcll(word), tmp, total);
   s_bits[threadIdx.x] = word; s_pref[threadIdx.x] = ex;
   __syncthreads();
-  const uint32_t base = a.parts[nd.part_base + tile];
+  const uint32_t base = sload32(a.parts + nd.part_base + tile);
   for (uint32_t i = wave_id(); i < W; i += 4) {
     const uint64_t ww = (uint64_t)tile * W + i;
     if (ww * 64 >= rows) break;
@@ -1541,9 +1825,9 @@ __device__ __forceinline__ void body_varint_decode(const KArgs& a, const NodeDes
     s_start[k++] = (uint16_t)(o0 + j);
   }
   __syncthreads();
-  if (tile == 0 && threadIdx.x == 0 && a.totals[nd.total_idx] < nd.rows) atomicOr(a.status, ST_VARINT_COUNT);
+  if (tile == 0 && threadIdx.x == 0 && sload32(a.totals + nd.total_idx) < nd.rows) atomicOr(a.status, ST_VARINT_COUNT);
   // pass 2
-  const uint64_t rank0 = a.parts[nd.part_base + tile];
+  const uint64_t rank0 = sload32(a.parts + nd.part_base + tile);
   for (uint32_t i = threadIdx.x; i < count; i += kBlock) {
     if (rank0 + i >= rows) break;
     const uint32_t off = s_start[i];
@@ -1599,7 +1883,7 @@ __device__ __forceinline__ void body_string_views(const KArgs& a, const NodeDesc
     s += len[j];
   }
   uint32_t total;
-  uint32_t off = block_excl_scan(s, tmp, total) + a.parts[nd.part_base + tile] + (uint32_t)nd.aux;
+  uint32_t off = block_excl_scan(s, tmp, total) + sload32(a.parts + nd.part_base + tile) + (uint32_t)nd.aux;
   uint64_t* dst = reinterpret_cast<uint64_t*>(self_ptr(nd, a));
   uint64_t v[8];
 #pragma unroll
@@ -1616,7 +1900,7 @@ __device__ __forceinline__ void body_string_views(const KArgs& a, const NodeDesc
     for (uint32_t j = 0; j < 8; ++j)
       if (e0 + j < n) dst[e0 + j] = v[j];
   }
-  if (tile == 0 && threadIdx.x == 0 && a.totals[nd.total_idx] > nd.aux2) atomicOr(a.status, ST_STRING_BYTES);
+  if (tile == 0 && threadIdx.x == 0 && sload32(a.totals + nd.total_idx) > nd.aux2) atomicOr(a.status, ST_STRING_BYTES);
 }
 
 // -------------------------------------------------------------- K_COPY_BYTES
@@ -1907,9 +2191,9 @@ __device__ __forceinline__ void single_op_kernel(const KArgs& a) {
   run_op<OP>(a, nd, tr.tile & kTileMask, smem, aux);
 }
 #define NBL_KERNEL_ES(name, KID) \
-  template <int ES> __global__ __launch_bounds__(256) void name(KArgs a) { single_op_kernel<make_op(KID, ES)>(a); }
+  template <int ES> __global__ __launch_bounds__(256, 8) void name(KArgs a) { single_op_kernel<make_op(KID, ES)>(a); }
 #define NBL_KERNEL(name, KID) \
-  __global__ __launch_bounds__(256) void name(KArgs a) { single_op_kernel<make_op(KID, 1)>(a); }
+  __global__ __launch_bounds__(256, 8) void name(KArgs a) { single_op_kernel<make_op(KID, 1)>(a); }
 NBL_KERNEL_ES(k_materialize, K_MATERIALIZE)
 NBL_KERNEL_ES(k_materialize_fbw, K_MATERIALIZE_FBW)
 NBL_KERNEL_ES(k_materialize_raw, K_MATERIALIZE_RAW)

@@ -89,6 +89,17 @@ struct PNode {
   // then names the uint32 indices and `alpha_ref` the alphabet element array
   bool fused_gather = false;
   ColRef alpha_ref{};
+  // MainlyConstant whose scatter its Nullable / MainlyConstant parent performs
+  // together with its own (NF_NESTED_SELECT): `ref` then names the other values,
+  // `sel_ref` the isCommon bitmap, and the rank partials stay this node's
+  bool fused_select = false;
+  ColRef sel_ref{};
+  uint32_t sel_part_base = 0, sel_total_idx = 0;
+  // RLE whose expansion its Nullable / MainlyConstant parent performs inside its
+  // rank scatter (NF_RLE_VALUES): `ref` then names the run values, `ends_ref` the
+  // run-end array in work (first_run[] behind it), sel_total_idx its totals slot
+  bool fused_runs = false;
+  ColRef ends_ref{};
   // result
   ColRef ref{};              // how a consumer reads this node
   int ready = 0;             // level after which `ref` is valid
@@ -533,9 +544,21 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
   // Nullable / MainlyConstant is not expanded into a column of its own: the
   // parent's rank scatter gathers from the alphabet itself, which saves writing
   // and re-reading every non-null row.
-  if ((nn.enc == ET_NULLABLE || nn.enc == ET_MAINLYCONSTANT) && !nn.is_bool && nn.es >= 4) {
+  if ((nn.enc == ET_NULLABLE || nn.enc == ET_MAINLYCONSTANT) && !nn.is_bool && nn.es >= 4 && !nn.fused_select) {
     PNode& vals = nodes[(size_t)nn.child[nn.enc == ET_NULLABLE ? 0 : 1]];
     if (vals.enc == ET_DICTIONARY && vals.rows > 0 && nodes[(size_t)vals.child[0]].rows > 0) vals.fused_gather = true;
+    // A MainlyConstant directly underneath (Nullable{MainlyConstant{..}}: sparse
+    // feature columns) is resolved by this node's rank scatter as well, so the
+    // inner column is never written and read back.  Its other values must be a
+    // column the scatter can read by index (anything but a Dictionary that would
+    // want its own fused gather).
+    if (vals.enc == ET_MAINLYCONSTANT && vals.rows > 0 && nodes[(size_t)vals.child[1]].enc != ET_DICTIONARY &&
+        !(root && keep_dictionary))
+      vals.fused_select = true;
+    // So is an RLE directly underneath (Nullable{RLE{..}}): the parent's scatter
+    // expands the runs; run ends and first_run[] are still prepared by the RLE's
+    // own steps.
+    if (vals.enc == ET_RLE && vals.rows > 0 && nodes[(size_t)vals.child[0]].rows > 0) vals.fused_runs = true;
   }
   // children first
   for (int s = 0; s < 3; ++s)
@@ -646,13 +669,22 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
         d.self = bits_ref();
         if (nn.flag) d.flags |= NF_FIRST_TRUE;
       } else {
-        d.self = mat_ref(es);
+        if (!nn.fused_runs) d.self = mat_ref(es);
         d.c1 = C(1).ref;
       }
       const uint32_t dn = add_dnode(d, /*aux_work=*/true);
       add_step(lvl, K_REDUCE_SUM, 4, dn, nt);
       add_step(lvl + 1, K_SCAN_TILES, 0, dn, 1, true);
       add_step(lvl + 2, K_RLE_ENDS, 4, dn, nt);
+      if (nn.fused_runs) {
+        // the parent expands: hand it the run ends (a work array, rebased with the
+        // other intermediates), the run values and the totals slot
+        nn.ends_ref.kind = COL_MAT_WORK; nn.ends_ref.off = d.aux_off; nn.ends_ref.rows = rows; nn.ends_ref.es = 4;
+        nn.sel_total_idx = d.total_idx;
+        nn.ref = d.c1; nn.ref.rows = R;
+        nn.ready = lvl + 3;
+        break;
+      }
       if (nn.is_bool) add_step(lvl + 3, K_RLE_EXPAND_BOOL, 0, dn, div_up32(rows, kBitTileRows));
       else add_step(lvl + 3, K_RLE_EXPAND, es, dn, div_up32(rows, tile_rows));
       nn.ref = d.self; nn.ready = lvl + 4;
@@ -725,6 +757,20 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
           d.aux = nn.value;
         }
       }
+      if (const PNode& vals = nullable ? C(0) : C(1); vals.fused_runs) {
+        d.c0 = vals.ends_ref;         // run ends (+ first_run[]); its rows = this node's ranks
+        d.c1 = vals.ref;              // run values, one per run
+        d.total_idx2 = vals.sel_total_idx;
+        d.flags |= NF_RLE_VALUES;
+      }
+      if (const PNode& vals = nullable ? C(0) : C(1); vals.fused_select) {
+        d.c0 = vals.sel_ref;          // the inner isCommon bitmap; its rows = this node's ranks
+        d.c1 = vals.ref;              // the inner other values
+        d.aux3 = vals.value;          // the inner common value (strings: its view)
+        d.part_base2 = vals.sel_part_base;
+        d.total_idx2 = vals.sel_total_idx;
+        d.flags |= NF_NESTED_SELECT;
+      }
       if (nullable && root) {
         d.flags |= NF_WRITE_NULLS;
         d.aux_off = layouts[(size_t)nn.chunk].nulls_offset;
@@ -733,12 +779,25 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       d.aux2 = trows;
       const uint32_t nt = div_up32(rows, trows);
       alloc_scan(d, nt);
-      d.self = nn.is_bool ? bits_ref() : mat_ref(es);
-      const uint32_t dn = add_dnode(d);
       // the ranks need the selection bitmap only: counted and scanned as soon as
       // that child is ready, underneath whatever the values child still has to do
       const int sel_lvl = (nullable ? C(1) : C(0)).ready;
       const int fin = std::max(lvl, sel_lvl + 2);
+      if (nn.fused_select) {
+        // the parent scatters for this node: it only counts and scans its ranks
+        const uint32_t dn = add_dnode(d);
+        add_step(sel_lvl, K_REDUCE_POPC, 0, dn, div_up32(rows, kPopcTileRows));
+        add_step(sel_lvl + 1, K_SCAN_TILES, 0, dn, 1, true);
+        nn.sel_ref = d.sel;
+        nn.sel_part_base = d.part_base;
+        nn.sel_total_idx = d.total_idx;
+        nn.value = d.aux;
+        nn.ref = d.c1;
+        nn.ready = fin;
+        break;
+      }
+      d.self = nn.is_bool ? bits_ref() : mat_ref(es);
+      const uint32_t dn = add_dnode(d);
       add_step(sel_lvl, K_REDUCE_POPC, 0, dn, div_up32(rows, kPopcTileRows));  // each tile emits the partials of kPopcTileRows / trows consumer tiles
       add_step(sel_lvl + 1, K_SCAN_TILES, 0, dn, 1, true);
       if (nn.is_bool) add_step(fin, K_SELECT_BITS, 0, dn, nt);

@@ -198,8 +198,9 @@ def test_leaf_only_chunks_fill_the_preparatory_levels():
 
 def test_rank_counting_is_placed_at_the_bitmap_level():
     """The popcount partials and their scan of a Nullable read the null bitmap
-    only: under a deep values child (RLE: sums, scan, run ends, expand) they run
-    alongside its first steps, and the rank scatter is the single extra level."""
+    only: under a deep values child (RLE: sums, scan, run ends) they run
+    alongside its first steps.  The rank scatter expands the runs itself, so the
+    RLE has no expand step and the scatter follows the run ends directly."""
     rng = np.random.default_rng(5)
     n = 300_000
     mask = rng.random(n) < 0.7
@@ -210,11 +211,41 @@ def test_rank_counting_is_placed_at_the_bitmap_level():
     for name, _, _, lvl, _ in p.launches():
         level.setdefault(name, lvl)
     assert level["k_reduce_popc"] == level["k_reduce_sum"] == 0
-    assert level["k_rle_expand<8>"] == 3 and level["k_select_scatter<8>"] == 4
+    assert "k_rle_expand<8>" not in level and level["k_rle_ends"] == 2 and level["k_select_scatter<8>"] == 3
     p.close()
     fused = Plan.from_encodings([enc])
-    assert int(fused.info.n_launches) == 5
+    assert int(fused.info.n_launches) == 4
     fused.close()
+
+
+def test_values_children_resolved_inside_the_rank_scatter():
+    """Nullable / MainlyConstant over a Dictionary, an RLE or a MainlyConstant of
+    4- or 8-byte rows: the parent's rank scatter gathers / expands / selects for
+    the child, which therefore has no step writing a column of its own.  Narrow
+    rows and bool keep the two-pass form."""
+    rng = np.random.default_rng(6)
+    n = 50_000
+    mask = rng.random(n) < 0.6
+    nn = int(mask.sum())
+
+    def names(enc):
+        p = Plan.from_encodings([enc], per_kernel=True)
+        out = [l[0] for l in p.launches()]
+        p.close()
+        return out
+
+    runs = np.repeat(rng.integers(0, 90, nn // 10 + 1), 10)[:nn]
+    got = names(E.encode_nullable(E.Nullable(data=E.RLE(), nulls=E.Trivial()), runs.astype(np.int32), mask, W.INT32))
+    assert "k_rle_ends" in got and not any(k.startswith("k_rle_expand") for k in got) and got.count("k_select_scatter<4>") == 1
+    got = names(E.encode_nullable(E.Nullable(data=E.RLE(), nulls=E.Trivial()), runs.astype(np.int16), mask, W.INT16))
+    assert "k_rle_expand<2>" in got and "k_select_scatter<2>" in got  # narrow rows: two passes
+    mc = np.where(rng.random(nn) < 0.9, 7, rng.integers(100, 1000, nn)).astype(np.int64)
+    got = names(E.encode_nullable(E.Nullable(data=E.MainlyConstant(), nulls=E.SparseBool()), mc, mask, W.INT64))
+    assert got.count("k_select_scatter<8>") == 1 and "k_reduce_popc" in got  # both nodes count ranks, one scatters
+    # nesting goes one deep: of three MainlyConstants the middle one is resolved by the outermost, the innermost scatters itself
+    v = np.where(rng.random(n) < 0.8, 1, np.where(rng.random(n) < 0.7, 2, rng.integers(3, 9, n))).astype(np.int32)
+    three = E.encode(E.MainlyConstant(other=E.MainlyConstant(other=E.MainlyConstant())), v, W.INT32)
+    assert names(three).count("k_select_scatter<4>") == 2
 
 
 def _rle_bytes(dtype, rows, lengths, values, varint_rows=False):
