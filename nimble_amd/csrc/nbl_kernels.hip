@@ -111,18 +111,40 @@ __device__ __forceinline__ uint64_t bits_word(const ColRef& c, const KArgs& a, u
       return 0;
   }
 }
-// Same with bits at or past `rows` cleared (w must address a word that starts before rows).
-__device__ __forceinline__ uint64_t bits_word_masked(const ColRef& c, const KArgs& a, uint64_t w, bool invert) {
-  uint64_t v = bits_word(c, a, w);
-  if (invert) v = ~v;
-  const uint64_t first = w * 64;
-  const uint64_t rows = c.rows;
-  if (first + 64 > rows) v &= wmask((uint32_t)(rows - first));
-  return v;
-}
 __device__ __forceinline__ uint32_t col_bit(const ColRef& c, const KArgs& a, uint64_t i) {
   return (uint32_t)(bits_word(c, a, i >> 6) >> (i & 63)) & 1u;
 }
+// How a bool column is read, fixed once per tile (the column descriptor is wave
+// uniform): word() is then one load with no branch around it, so several words
+// are requested back to back.  Through bits_word() every load sits inside a
+// switch over the column kind and the compiler waits for each before it issues
+// the next -- one memory round trip per word on the tile's critical path.
+struct BitsReader {
+  const uint8_t* p;  // bitmap bytes, any alignment; a readable dummy for a constant column
+  uint64_t konst;    // constant column: every word
+  uint64_t flip;     // all ones when the column is read inverted
+  uint64_t rows;
+  bool is_const;
+  __device__ __forceinline__ BitsReader(const ColRef& c, const KArgs& a, bool invert) {
+    is_const = !(c.kind == COL_BITS_WORK || c.kind == COL_BITS_RAW);
+    p = is_const ? a.work : (c.kind == COL_BITS_WORK ? a.work : a.arena) + c.off;
+    konst = (c.kind == COL_CONST && c.base) ? ~0ull : 0ull;
+    flip = invert ? ~0ull : 0ull;
+    rows = c.rows;
+  }
+  // bits [64 w, 64 w + 64), bits at or past `rows` undefined
+  __device__ __forceinline__ uint64_t raw(uint64_t w) const {
+    const uint64_t v = ldu64(p + (is_const ? 0ull : 8ull * w));
+    return (is_const ? konst : v) ^ flip;
+  }
+  // the same with bits at or past `rows` cleared (w must address a word that starts before rows)
+  __device__ __forceinline__ uint64_t word(uint64_t w) const {
+    uint64_t v = raw(w);
+    const uint64_t first = w * 64;
+    if (first + 64 > rows) v &= wmask((uint32_t)(rows - first));
+    return v;
+  }
+};
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t wave_id() { return threadIdx.x >> 6; }
@@ -698,7 +720,7 @@ __device__ __forceinline__ void body_materialize(const KArgs& a, const NodeDesc&
 // Bool bitmap -> one byte per row, what Encoding::materialize yields for bool
 // (TrivialEncoding<bool>::materialize, encodings/TrivialEncoding.cpp:329-368).
 __device__ __forceinline__ void body_bits_to_bytes(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t*) {
-  const ColRef src = nd.c0;
+  const BitsReader bits(nd.c0, a, false);
   const uint64_t rows = nd.rows;
   const uint64_t start = (uint64_t)tile * kTileBytes;
   uint8_t* dst = self_ptr(nd, a);
@@ -706,7 +728,7 @@ __device__ __forceinline__ void body_bits_to_bytes(const KArgs& a, const NodeDes
 #pragma unroll
   for (uint32_t it = 0; it < 4; ++it) {
     const uint64_t e0 = start + (uint64_t)(it * kBlock + threadIdx.x) * 16;
-    word[it] = bits_word(src, a, (e0 < rows ? e0 : rows - 1) >> 6);  // clamped: every lane loads
+    word[it] = bits.raw((e0 < rows ? e0 : rows - 1) >> 6);  // clamped: every lane loads
   }
 #pragma unroll
   for (uint32_t it = 0; it < 4; ++it) {
@@ -748,12 +770,12 @@ __device__ __forceinline__ void body_reduce_sum(const KArgs& a, const NodeDesc& 
 __device__ __forceinline__ void body_reduce_popc(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
   uint32_t* tmp = reinterpret_cast<uint32_t*>(smem);
   const uint32_t sub = (uint32_t)(nd.aux2 >> 6);  // words per consumer tile
-  const bool invert = (nd.flags & NF_INVERT_SEL) != 0;
+  const BitsReader sel(nd.sel, a, (nd.flags & NF_INVERT_SEL) != 0);
   uint32_t cnt[kPopcWordsPerThread];
 #pragma unroll
   for (uint32_t u = 0; u < kPopcWordsPerThread; ++u) {
     const uint64_t w = ((uint64_t)tile * kPopcWordsPerThread + u) * kBitTileWords + threadIdx.x;
-    cnt[u] = w * 64 < nd.sel.rows ? (uint32_t)__popcll(bits_word_masked(nd.sel, a, w, invert)) : 0u;
+    cnt[u] = w * 64 < nd.sel.rows ? (uint32_t)__popcll(sel.word(w)) : 0u;
   }
 #pragma unroll
   for (uint32_t u = 0; u < kPopcWordsPerThread; ++u) {
@@ -1339,8 +1361,11 @@ __device__ __forceinline__ void select_nested(const KArgs& a, const NodeDesc& nd
   uint64_t iw0 = 0, iw1 = 0;
   const uint32_t l = threadIdx.x - 64;
   if (threadIdx.x >= 64 && threadIdx.x < 128) {
-    if (l < nw) iw0 = bits_word_masked(nd.c0, a, w0 + l, inv2);
-    if (l + 64 < nw) iw1 = bits_word_masked(nd.c0, a, w0 + l + 64, inv2);
+    const BitsReader inner(nd.c0, a, inv2);
+    const uint64_t r0 = inner.word(w0 + (l < nw ? l : 0));               // both requested before either is used
+    const uint64_t r1 = inner.word(w0 + (l + 64 < nw ? l + 64 : 0));
+    iw0 = l < nw ? r0 : 0;
+    iw1 = l + 64 < nw ? r1 : 0;
   }
   StageRegs<5> regs;
   regs.nvec = 0;
@@ -1484,7 +1509,7 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
   const uint32_t n = count < avail ? count : avail;
   const uint64_t w = (uint64_t)tile * W + threadIdx.x;
   uint64_t word = 0;
-  if (threadIdx.x < W && w * 64 < rows) word = bits_word_masked(nd.sel, a, w, invert);
+  if (threadIdx.x < W && w * 64 < rows) word = BitsReader(nd.sel, a, invert).word(w);
   const T fill = (T)nd.aux;
   auto write_nulls = [&]() {
     if ((nd.flags & NF_WRITE_NULLS) && threadIdx.x < W && w * 64 < rows)
@@ -1618,7 +1643,7 @@ __device__ __forceinline__ void body_select_bits(const KArgs& a, const NodeDesc&
   const uint64_t w = (uint64_t)tile * W + threadIdx.x;
   uint64_t word = 0;
   if (w * 64 < rows) {
-    word = bits_word_masked(nd.sel, a, w, false);
+    word = BitsReader(nd.sel, a, false).word(w);
     if (nd.flags & NF_WRITE_NULLS) reinterpret_cast<uint64_t*>(a.out + nd.aux_off)[w] = word;
   }
   uint32_t total;

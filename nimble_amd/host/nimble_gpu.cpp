@@ -170,21 +170,42 @@ class PinnedPool : public std::enable_shared_from_this<PinnedPool> {
 
 }  // namespace
 
+// A context owns two slots, each a stream with device buffers of its own.
+// Consecutive batches alternate slots, so the host-to-device copy and the
+// decode of one stripe run while the decoded output of the stripe before is
+// still on its way back on the other stream (the link is full duplex): the
+// stripe loop of a reader (VeloxReader::loadNextStripe, velox/VeloxReader.cpp:330-351)
+// then pays the longer of the two transfers per stripe instead of their sum.
+// A slot is reused by the batch after next, which queues on the slot's stream
+// behind the copy-back that still reads its output buffer.
 class GpuContext {
  public:
+  struct Slot {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    DeviceBuffer arena, out, work;
+  };
   explicit GpuContext(int device) : device_(device) {}
   ~GpuContext() {
-    if (stream_) (void)hipStreamDestroy(stream_);
+    for (Slot& s : slots_)
+      if (s.stream) {
+        (void)hipStreamSynchronize(s.stream);
+        (void)hipStreamDestroy(s.stream);
+      }
   }
-  std::mutex mu;
   int device_;
-  hipStream_t stream_ = nullptr;
-  DeviceBuffer arena, out, work;
   std::shared_ptr<PinnedPool> pinned = std::make_shared<PinnedPool>();
-  void ensure() {
+  // the slot of the next batch; the caller locks slot.mu around its use of the slot
+  Slot& nextSlot() { return slots_[next_.fetch_add(1, std::memory_order_relaxed) % kSlots]; }
+  void ensure(Slot& s) {
     hipCheck(hipSetDevice(device_), "hipSetDevice");
-    if (!stream_) hipCheck(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking), "hipStreamCreate");
+    if (!s.stream) hipCheck(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "hipStreamCreate");
   }
+
+ private:
+  static constexpr unsigned kSlots = 2;
+  Slot slots_[kSlots];
+  std::atomic<unsigned> next_{0};
 };
 
 namespace {
@@ -510,19 +531,21 @@ std::vector<std::unique_ptr<Encoding>> decodeChunks(GpuContext& ctx, const std::
 
   auto hostOut = std::make_shared<OutputCopy>(ctx.pinned->acquire(info.out_bytes));
   {
-    std::lock_guard<std::mutex> lock(ctx.mu);
-    ctx.ensure();
-    ctx.arena.reserve(info.arena_bytes);
-    ctx.out.reserve(info.out_bytes);
-    ctx.work.reserve(info.work_bytes);
-    hipCheck(hipMemcpyAsync(ctx.arena.ptr, staging.get(), total, hipMemcpyHostToDevice, ctx.stream_), "H2D");
-    check(nbl_plan_upload(plan.p, ctx.work.ptr, ctx.stream_));
-    check(nbl_decode_batch_device(plan.p, ctx.arena.ptr, ctx.out.ptr, ctx.work.ptr, ctx.stream_));
-    // synchronises the stream: inconsistent payloads are reported before anything is handed out
-    check(nbl_decode_status(plan.p, ctx.work.ptr, ctx.stream_));
-    // the copy back runs on while the caller already reads the first chunks; a
-    // later batch of this context queues behind it on the same stream
-    hostOut->enqueue(ctx.out.ptr, info.out_bytes, ctx.stream_);
+    GpuContext::Slot& slot = ctx.nextSlot();
+    std::lock_guard<std::mutex> lock(slot.mu);
+    ctx.ensure(slot);
+    slot.arena.reserve(info.arena_bytes);
+    slot.out.reserve(info.out_bytes);
+    slot.work.reserve(info.work_bytes);
+    hipCheck(hipMemcpyAsync(slot.arena.ptr, staging.get(), total, hipMemcpyHostToDevice, slot.stream), "H2D");
+    check(nbl_plan_upload(plan.p, slot.work.ptr, slot.stream));
+    check(nbl_decode_batch_device(plan.p, slot.arena.ptr, slot.out.ptr, slot.work.ptr, slot.stream));
+    // synchronises the slot's stream: inconsistent payloads are reported before anything is handed out
+    check(nbl_decode_status(plan.p, slot.work.ptr, slot.stream));
+    // the copy back runs on while the caller already reads the first chunks and
+    // while the next batch is copied in and decoded on the other slot; the batch
+    // after that queues behind this copy on this slot's stream
+    hostOut->enqueue(slot.out.ptr, info.out_bytes, slot.stream);
   }
   result.reserve(chunks.size());
   for (uint32_t c = 0; c < chunks.size(); ++c) {
@@ -540,8 +563,9 @@ class DeviceBatchImpl final : public DeviceBatch {
   const void* data() const override { return out.ptr; }
   uint64_t bytes() const override { return outBytes; }
   int device() const override { return ctx->device_; }
-  void* stream() const override { return ctx->stream_; }
+  void* stream() const override { return stream_; }
   std::shared_ptr<GpuContext> ctx;
+  hipStream_t stream_ = nullptr;
   DeviceBuffer out;
   uint64_t outBytes = 0;
   std::vector<nbl_chunk_layout> layouts;
@@ -580,16 +604,18 @@ std::unique_ptr<DeviceBatch> decodeChunksToDevice(const std::shared_ptr<GpuConte
   nbl_plan_info info;
   check(nbl_plan_get_info(plan.p, &info));
   {
-    std::lock_guard<std::mutex> lock(ctx.mu);
-    ctx.ensure();
-    ctx.arena.reserve(info.arena_bytes);
-    ctx.work.reserve(info.work_bytes);
+    GpuContext::Slot& slot = ctx.nextSlot();
+    std::lock_guard<std::mutex> lock(slot.mu);
+    ctx.ensure(slot);
+    slot.arena.reserve(info.arena_bytes);
+    slot.work.reserve(info.work_bytes);
     batch->out.reserve(info.out_bytes);   // owned by the batch: it outlives this call
     batch->outBytes = info.out_bytes;
-    hipCheck(hipMemcpyAsync(ctx.arena.ptr, staging.get(), total, hipMemcpyHostToDevice, ctx.stream_), "H2D");
-    check(nbl_plan_upload(plan.p, ctx.work.ptr, ctx.stream_));
-    check(nbl_decode_batch_device(plan.p, ctx.arena.ptr, batch->out.ptr, ctx.work.ptr, ctx.stream_));
-    check(nbl_decode_status(plan.p, ctx.work.ptr, ctx.stream_));  // synchronises the stream
+    batch->stream_ = slot.stream;
+    hipCheck(hipMemcpyAsync(slot.arena.ptr, staging.get(), total, hipMemcpyHostToDevice, slot.stream), "H2D");
+    check(nbl_plan_upload(plan.p, slot.work.ptr, slot.stream));
+    check(nbl_decode_batch_device(plan.p, slot.arena.ptr, batch->out.ptr, slot.work.ptr, slot.stream));
+    check(nbl_decode_status(plan.p, slot.work.ptr, slot.stream));  // synchronises the slot's stream
   }
   batch->layouts.resize(chunks.size());
   for (uint32_t c = 0; c < chunks.size(); ++c) check(nbl_plan_get_chunk_layout(plan.p, c, &batch->layouts[c]));

@@ -3,9 +3,15 @@
 // build:  g++ -O2 -std=c++17 -Iinclude -Inimble_amd/host tools/host_bench.cpp -o tools/bin/host_bench \
 //             -Lnimble_amd/_lib -lnimble_amd_host -lnimble_amd -Wl,-rpath,'$ORIGIN/../../nimble_amd/_lib'
 // input:  tools/dump_workload.py <workload> <prefix>  ->  <prefix>.bin, <prefix>.off
-// usage:  host_bench <prefix> [iterations] [reader threads]   (readers > 1: the chunks are materialised by that
-//         many threads, each with a buffer of its own, as the reference's field readers run on an executor)
+// usage:  host_bench <prefix> [iterations] [reader threads] [pipeline]
+//         readers > 1: the chunks are materialised by that many threads, each with a buffer of its own, as the
+//         reference's field readers run on an executor; pipeline = 1: the stripes (iterations) are decoded as a
+//         reader's stripe loop would drive them -- createBatch of stripe n+1 runs on a loader thread while the
+//         readers drain stripe n -- and one line gives the rate over all stripes
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <deque>
 #include <chrono>
 #include <cstdio>
 #include <algorithm>
@@ -43,6 +49,97 @@ int main(int argc, char** argv) {
   }
   std::vector<std::string_view> chunks;
   for (size_t i = 0; i + 1 < off.size(); i += 2) chunks.emplace_back(buf.data() + off[i], off[i + 1]);
+  const bool pipeline = argc > 4 && atoi(argv[4]) != 0;
+  auto elem_size = [](const Encoding& e) -> size_t {
+    const DataType t = e.dataType();
+    return t == DataType::String ? sizeof(std::string_view) : t == DataType::Bool ? 1
+           : (t == DataType::Int64 || t == DataType::Uint64 || t == DataType::Double) ? 8
+           : (t == DataType::Int32 || t == DataType::Uint32 || t == DataType::Float) ? 4
+           : (t == DataType::Int16 || t == DataType::Uint16) ? 2 : 1;
+  };
+  if (pipeline) {
+    try {
+      GpuEncodingFactory factory;
+      struct Stripe {
+        std::vector<std::unique_ptr<Encoding>> encs;
+        std::vector<std::unique_ptr<char[]>> strings;
+      };
+      std::mutex mu;
+      std::condition_variable cv;
+      std::deque<std::unique_ptr<Stripe>> ready;  // at most one decoded stripe waits while another is drained
+      bool done = false;
+      std::string error;
+      { auto warm = factory.createBatch(chunks, [](uint32_t n) -> void* { static std::vector<std::unique_ptr<char[]>> keep; keep.push_back(std::make_unique<char[]>(n ? n : 1)); return keep.back().get(); }, factory.options()); }
+      const auto t0 = Clock::now();
+      std::thread loader([&] {
+        try {
+          for (int it = 0; it < iters; ++it) {
+            auto st = std::make_unique<Stripe>();
+            auto* strings = &st->strings;
+            st->encs = factory.createBatch(chunks, [strings](uint32_t n) -> void* { strings->push_back(std::make_unique<char[]>(n ? n : 1)); return strings->back().get(); }, factory.options());
+            std::unique_lock<std::mutex> lock(mu);
+            cv.wait(lock, [&] { return ready.size() < 1; });
+            ready.push_back(std::move(st));
+            cv.notify_all();
+          }
+        } catch (const std::exception& e) { std::lock_guard<std::mutex> lock(mu); error = e.what(); }
+        std::lock_guard<std::mutex> lock(mu);
+        done = true;
+        cv.notify_all();
+      });
+      uint64_t rows = 0, bytes = 0;
+      std::vector<std::vector<uint8_t>> sinks((size_t)readers);
+      // the first stripes also pay for the pinned blocks of every stripe in flight (hipHostMalloc of a few GB):
+      // the steady-state rate is taken over the stripes after them
+      constexpr int kWarm = 3;
+      int drained = 0;
+      Clock::time_point t_steady = t0;
+      uint64_t bytes_at_steady = 0;
+      for (;;) {
+        std::unique_ptr<Stripe> st;
+        {
+          std::unique_lock<std::mutex> lock(mu);
+          cv.wait(lock, [&] { return !ready.empty() || done; });
+          if (ready.empty()) break;
+          st = std::move(ready.front());
+          ready.pop_front();
+          cv.notify_all();
+        }
+        std::atomic<size_t> next{0};
+        std::atomic<uint64_t> r{0}, b{0};
+        auto drain = [&](std::vector<uint8_t>& sink) {
+          for (size_t c = next++; c < st->encs.size(); c = next++) {
+            auto& e = st->encs[c];
+            const uint32_t n = e->rowCount();
+            const size_t es = elem_size(*e);
+            if (sink.size() < (size_t)n * es) sink.resize((size_t)n * es);
+            e->materialize(n, sink.data());
+            r += n;
+            b += (uint64_t)n * (e->dataType() == DataType::String ? 8 : es);
+          }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < readers; ++t) pool.emplace_back([&, t] { drain(sinks[(size_t)t]); });
+        drain(sinks[0]);
+        for (auto& t : pool) t.join();
+        rows += r.load();
+        bytes += b.load();
+        if (++drained == kWarm) { t_steady = Clock::now(); bytes_at_steady = bytes; }
+      }
+      loader.join();
+      if (!error.empty()) { fprintf(stderr, "error: %s\n", error.c_str()); return 1; }
+      const auto t1 = Clock::now();
+      printf("pipelined: %d stripes, %d readers: %.2f ms per stripe, rows %llu, decoded %.3f GB, end-to-end %.2f GB/s\n", iters, readers,
+             ms(t0, t1) / iters, (unsigned long long)rows, bytes / 1e9, bytes / 1e6 / ms(t0, t1));
+      if (drained > kWarm)
+        printf("steady state (stripes %d..%d): %.2f ms per stripe, end-to-end %.2f GB/s\n", kWarm, drained - 1,
+               ms(t_steady, t1) / (drained - kWarm), (bytes - bytes_at_steady) / 1e6 / ms(t_steady, t1));
+    } catch (const std::exception& e) {
+      fprintf(stderr, "error: %s\n", e.what());
+      return 1;
+    }
+    return 0;
+  }
   try {
     GpuEncodingFactory factory;
     std::vector<std::unique_ptr<char[]>> strings;
