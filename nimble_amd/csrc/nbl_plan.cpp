@@ -928,10 +928,27 @@ void nbl_plan::spread_free_steps(int last_level) {
     else fixed[(size_t)st.level] += st.n_tiles;
   }
   if (free_tiles == 0) return;
-  // level l takes free tiles up to the common target; what does not fit goes to the last level
-  const uint64_t target = (all_tiles + n_levels - 1) / n_levels;
+  // Water filling: the free tiles raise the emptiest levels to a common height.
+  // With plenty of them every level ends up with the same number of tiles; with
+  // few, they are shared out among the preparatory levels -- each of which costs
+  // its chain of dependent loads whatever else it carries -- instead of all
+  // going into the first one.
   std::vector<uint64_t> room(n_levels, 0);
-  for (size_t l = 0; l < n_levels; ++l) room[l] = target > fixed[l] ? target - fixed[l] : 0;
+  {
+    std::vector<size_t> order(n_levels);
+    for (size_t l = 0; l < n_levels; ++l) order[l] = l;
+    std::sort(order.begin(), order.end(), [&](size_t a, size_t b) { return fixed[a] < fixed[b]; });
+    uint64_t pool = free_tiles, height = fixed[order[0]];
+    size_t k = 1;  // levels order[0..k) are being raised together
+    while (pool > 0) {
+      const uint64_t next = k < n_levels ? fixed[order[k]] : UINT64_MAX;
+      const uint64_t need = next == UINT64_MAX ? UINT64_MAX : (next - height) * k;  // tiles to reach the next level's height
+      if (need <= pool) { pool -= need; height = next; ++k; }
+      else { height += (pool + k - 1) / k; pool = 0; }
+    }
+    for (size_t i = 0; i < k && i < n_levels; ++i) room[order[i]] = height > fixed[order[i]] ? height - fixed[order[i]] : 0;
+  }
+  (void)all_tiles;
   size_t level = 0;
   std::vector<Step> pieces;
   for (size_t i : free_steps) {
