@@ -222,3 +222,23 @@ def test_bulk_fixed_bit_array_path_equals_the_element_wise_one():
     assert O.lib().orc_decode_all(buf.ctypes.data, buf.size, 0, a.ctypes.data, None) == runs.size
     assert O.lib().orc_decode_all_fast(buf.ctypes.data, buf.size, 0, b.ctypes.data, None) == runs.size
     assert np.array_equal(a, b) and np.array_equal(a[: runs.size], runs)
+
+
+def test_find_set_bit_property(oracle):
+    """The property BitsTests.cpp:67-83 states for velox's findSetBit, which the stream
+    stitching relies on (ChunkedStreamDecoder.cpp:103-110): with every third bit of
+    [begin, size) set at random and n = (size - begin) / 3, the answer is the position
+    of the n-th set bit, or `size` when fewer than n are set (n = 0 never matches)."""
+    rng = np.random.default_rng(67)
+    L = oracle.lib()
+    for _ in range(10):
+        size = int(rng.integers(1, 64 * 1024 + 1))
+        begin = int(rng.integers(0, size))
+        n = (size - begin) // 3
+        bits = np.zeros(size, dtype=bool)
+        bits[begin:] = rng.integers(0, 3, size - begin) == 0
+        packed = np.packbits(bits, bitorder="little")
+        packed = np.concatenate([packed, np.zeros(8, np.uint8)])
+        set_positions = np.flatnonzero(bits)
+        want = int(set_positions[n - 1]) if 0 < n <= set_positions.size else size
+        assert L.orc_find_set_bit(packed.ctypes.data, begin, size, n) == want
