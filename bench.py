@@ -60,6 +60,7 @@ def parse_args(argv=None):
     ap.add_argument("--stripes", type=int, default=0, help="strong scaling: stripes of the table (default 8 mixed / 16 wide)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pcie", action="store_true", help="skip the H2D+decode+D2H measurement")
+    ap.add_argument("--event-every", type=int, default=4, help="record the per-launch HIP events on every N-th timed step")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the per-operation profile of the unfused plan")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the short runs of the other benchmark tables")
     ap.add_argument("--check", action="store_true", help="verify a sample of the output against the oracle")
@@ -395,18 +396,21 @@ def roofline_of(by, workload, rows, launches_per_step_of=1):
 def short_run(workload, rows, device, torch, steps=5, warmup=2):
     """One of the other benchmark tables, outside the headline's timed region:
     `steps` passes over one stripe, wall clock between device synchronisations,
-    per-launch HIP events for the roofline of its dominant kernel."""
+    then as many passes with per-launch HIP events for the roofline of its
+    dominant kernel."""
     job = Job(workload, rows, [0], device)
     for _ in range(warmup):
         job.decode()
     job.status()
-    job.profile_begin(steps)
     torch.cuda.synchronize(device)
     t0 = time.perf_counter()
     for s in range(steps):
-        job.decode_profiled(s)
+        job.decode()
     torch.cuda.synchronize(device)
     dt = (time.perf_counter() - t0) / steps
+    job.profile_begin(steps)  # a second pass with the per-launch events (each costs a few microseconds of stream time)
+    for s in range(steps):
+        job.decode_profiled(s)
     ms = job.profile_end()
     job.status()
     by = by_kernel(job.launch_list, ms)
@@ -470,14 +474,20 @@ def main():
 
     # timed region: exactly K steps between barrier + device synchronise on both
     # sides, max over ranks; per-launch HIP events recorded on the decode stream
-    job.profile_begin(args.steps)
+    # on every `event_every`-th step (an event between two launches holds the stream
+    # for about 5 us, which a step of 0.2-0.5 ms would otherwise pay three times)
+    every = max(1, args.event_every)
+    job.profile_begin((args.steps + every - 1) // every)
     ev0 = torch.cuda.Event(enable_timing=True)
     ev1 = torch.cuda.Event(enable_timing=True)
 
     def step(s):
         if s == 0:
             ev0.record()
-        job.decode_profiled(s)
+        if s % every == 0:
+            job.decode_profiled(s // every)
+        else:
+            job.decode()
         if s == args.steps - 1:
             ev1.record()
 
@@ -524,6 +534,7 @@ def main():
         "decoded_bytes_total": total_decoded, "encoded_bytes_total": total_encoded,
         "decoded_bytes_rank0": job.decoded, "encoded_bytes_rank0": job.encoded,
         "device_ms_per_step": round(dev_ms / args.steps, 4),
+        "launch_events_on_steps": (args.steps + every - 1) // every,
         "whole_batch_algorithmic_gbs": round(whole, 1),
         "whole_batch_hbm_frac": round(whole / HBM_PEAK_GBS, 4),
         "roofline": roofline,

@@ -204,7 +204,10 @@ nbl_status nbl_decode_batch_device(const nbl_plan* plan, const void* d_arena,
 
 /* Synchronises `stream` and reports whether any kernel flagged inconsistent
  * data (e.g. run lengths that do not sum to the row count, dictionary index
- * out of range): NBL_OK or NBL_ERR_DEVICE_DATA. */
+ * out of range): NBL_OK or NBL_ERR_DEVICE_DATA.  The flags live in `d_work`
+ * and gather over every decode since nbl_plan_upload or the last call that
+ * reported them (reporting clears them), so one call after a series of
+ * decodes with the same plan covers the series. */
 nbl_status nbl_decode_status(const nbl_plan* plan, const void* d_work, void* stream);
 
 /* One kernel launch of the plan (for profiling and roofline accounting). */

@@ -94,6 +94,8 @@ enum NodeFlags : uint32_t {
   NF_NESTED_SELECT = 1u << 6,  // K_SELECT_SCATTER: the values child is a MainlyConstant resolved here as well: c0 = its
                                // isCommon bitmap (other values where the bit is 0), c1 = its other values, aux3 = its
                                // common value, part_base2 / total_idx2 = its scanned rank partials and total
+  NF_EMIT_PARTS = 1u << 8,   // K_SPARSE_BITS: the bitmap is the selection of its parent; also write the parent's rank
+                             // partials (part_base, aux2 = rows per parent tile; NF_INVERT_SEL: count the zero bits)
   NF_FRAME_BITS = 1u << 4,   // K_FRAME_UNPACK: FOR (u64 bit offsets, no raw marker) instead of
                              // BlockBitPacking (u32 byte offsets, width 255 = raw block)
 };

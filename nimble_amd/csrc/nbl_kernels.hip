@@ -763,24 +763,15 @@ __device__ __forceinline__ void body_reduce_sum(const KArgs& a, const NodeDesc& 
   if (threadIdx.x == 0) a.parts[nd.part_base + tile] = tot;
 }
 
-// Set bits of the selection bitmap per consumer tile.  One workgroup counts
-// kPopcTileRows rows (kPopcWordsPerThread 64-bit words per thread, all loaded
-// before the first is counted) and emits one partial per consumer tile of
-// nd.aux2 rows (32, 64, 128 or 256 words).
-__device__ __forceinline__ void body_reduce_popc(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
-  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem);
-  const uint32_t sub = (uint32_t)(nd.aux2 >> 6);  // words per consumer tile
-  const BitsReader sel(nd.sel, a, (nd.flags & NF_INVERT_SEL) != 0);
-  uint32_t cnt[kPopcWordsPerThread];
+// Rank partials of kPopcWordsPerThread * kBlock consecutive bitmap words, word
+// (tile * kPopcWordsPerThread + u) * kBlock + threadIdx.x counted in cnt[u]: one
+// partial per consumer tile of `sub` words (32, 64, 128 or 256) to parts[part_base + ..].
+__device__ __forceinline__ void emit_rank_partials(const KArgs& a, uint32_t part_base, uint32_t sub, uint64_t rows, uint32_t tile,
+                                                   const uint32_t (&cnt)[kPopcWordsPerThread], uint32_t* tmp) {
 #pragma unroll
   for (uint32_t u = 0; u < kPopcWordsPerThread; ++u) {
     const uint64_t w = ((uint64_t)tile * kPopcWordsPerThread + u) * kBitTileWords + threadIdx.x;
-    cnt[u] = w * 64 < nd.sel.rows ? (uint32_t)__popcll(sel.word(w)) : 0u;
-  }
-#pragma unroll
-  for (uint32_t u = 0; u < kPopcWordsPerThread; ++u) {
-    const uint64_t w = ((uint64_t)tile * kPopcWordsPerThread + u) * kBitTileWords + threadIdx.x;
-    const bool live = w * 64 < nd.sel.rows;
+    const bool live = w * 64 < rows;
     uint32_t s = cnt[u];
 #pragma unroll
     for (int d = 16; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);  // sum of the aligned 32-lane group
@@ -791,8 +782,23 @@ __device__ __forceinline__ void body_reduce_popc(const KArgs& a, const NodeDesc&
       __syncthreads();
       s = sub == 128 ? tmp[wave_id() & 2u] + tmp[(wave_id() & 2u) + 1] : tmp[0] + tmp[1] + tmp[2] + tmp[3];
     }
-    if (live && (threadIdx.x & (sub - 1)) == 0) a.parts[nd.part_base + (uint32_t)(w / sub)] = s;
+    if (live && (threadIdx.x & (sub - 1)) == 0) a.parts[part_base + (uint32_t)(w / sub)] = s;
   }
+}
+
+// Set bits of the selection bitmap per consumer tile.  One workgroup counts
+// kPopcTileRows rows (kPopcWordsPerThread 64-bit words per thread, all loaded
+// before the first is counted) and emits one partial per consumer tile of
+// nd.aux2 rows.
+__device__ __forceinline__ void body_reduce_popc(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
+  const BitsReader sel(nd.sel, a, (nd.flags & NF_INVERT_SEL) != 0);
+  uint32_t cnt[kPopcWordsPerThread];
+#pragma unroll
+  for (uint32_t u = 0; u < kPopcWordsPerThread; ++u) {
+    const uint64_t w = ((uint64_t)tile * kPopcWordsPerThread + u) * kBitTileWords + threadIdx.x;
+    cnt[u] = w * 64 < nd.sel.rows ? (uint32_t)__popcll(sel.word(w)) : 0u;
+  }
+  emit_rank_partials(a, nd.part_base, (uint32_t)(nd.aux2 >> 6), nd.sel.rows, tile, cnt, reinterpret_cast<uint32_t*>(smem));
 }
 
 // A varint starts at payload byte b when b == 0 or byte b-1 has its high bit
@@ -843,6 +849,7 @@ __device__ __forceinline__ void body_scan_tiles(const KArgs& a, const NodeDesc& 
   }
   if (threadIdx.x == 0) {
     a.totals[nd.total_idx] = carry;
+    a.totals[nd.total_idx + 1] = 0;  // the node's flag word (zero-length runs): set again by the steps after this one
     p[n] = carry;  // so that tile t's share is p[t + 1] - p[t] for every t
   }
 }
@@ -1172,16 +1179,26 @@ __device__ __forceinline__ void body_sparse_bits(const KArgs& a, const NodeDesc&
     }
   });
   __syncthreads();
+  // The parent that selects by this bitmap takes its rank partials from here
+  // (NF_EMIT_PARTS: part_base / aux2 are the parent's, NF_INVERT_SEL = it
+  // selects the zero bits), so no counting pass reads the bitmap back.
+  static_assert(WPT == kPopcWordsPerThread && kBlock == kBitTileWords, "same word layout as the counting pass");
+  const bool emit = (nd.flags & NF_EMIT_PARTS) != 0, zeros = (nd.flags & NF_INVERT_SEL) != 0;
+  uint32_t cnt[WPT];
 #pragma unroll
   for (uint32_t u = 0; u < WPT; ++u) {
     const uint64_t w = (uint64_t)tile * W + u * kBlock + threadIdx.x;
+    cnt[u] = 0;
     if (w * 64 < rows) {
       uint64_t v = s_bits[u * kBlock + threadIdx.x];
       if (!(nd.flags & NF_SPARSE_VALUE)) v = ~v;
-      if (w * 64 + 64 > rows) v &= wmask((uint32_t)(rows - w * 64));
+      const uint64_t m = w * 64 + 64 > rows ? wmask((uint32_t)(rows - w * 64)) : ~0ull;
+      v &= m;
       dst[w] = v;
+      cnt[u] = (uint32_t)__popcll(zeros ? ~v & m : v);
     }
   }
+  if (emit) emit_rank_partials(a, nd.part_base, (uint32_t)(nd.aux2 >> 6), rows, tile, cnt, reinterpret_cast<uint32_t*>(smem));
 }
 
 // ---------------------------------------------------------- K_SELECT_SCATTER

@@ -100,6 +100,9 @@ struct PNode {
   // run-end array in work (first_run[] behind it), sel_total_idx its totals slot
   bool fused_runs = false;
   ColRef ends_ref{};
+  // SparseBool: descriptor of its positions -> bitmap step (-1: none), so that a
+  // parent selecting by the bitmap can have that step count its rank partials
+  int sparse_dn = -1;
   // result
   ColRef ref{};              // how a consumer reads this node
   int ready = 0;             // level after which `ref` is valid
@@ -156,7 +159,7 @@ struct nbl_plan {
   int cur_chunk = -1;         // chunk being planned
   std::vector<uint8_t> blob;  // NodeDesc[] | TileRef[] image uploaded to work
   uint64_t tiles_off = 0, aux_off = 0;
-  uint64_t ctrl_off = 0, ctrl_bytes = 0;   // status word + per-node totals (zeroed per decode)
+  uint64_t ctrl_off = 0, ctrl_bytes = 0;   // status word + per-node totals (zeroed by the upload)
   uint64_t parts_off = 0;
   uint32_t n_parts = 0, n_totals = 0;
   uint64_t out_bytes = 0, work_bytes = 0, desc_bytes = 0;
@@ -698,6 +701,7 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       if (nn.flag) d.flags |= NF_SPARSE_VALUE;
       const uint32_t dn = add_dnode(d);
       add_step(lvl, K_SPARSE_BITS, 0, dn, div_up32(rows, kSparseTileRows));
+      if (rows > 0) nn.sparse_dn = (int)dn;
       nn.ref = d.self; nn.ready = lvl + 1;
       break;
     }
@@ -780,14 +784,25 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       const uint32_t nt = div_up32(rows, trows);
       alloc_scan(d, nt);
       // the ranks need the selection bitmap only: counted and scanned as soon as
-      // that child is ready, underneath whatever the values child still has to do
-      const int sel_lvl = (nullable ? C(1) : C(0)).ready;
-      const int fin = std::max(lvl, sel_lvl + 2);
+      // that child is ready, underneath whatever the values child still has to do.
+      // A SparseBool selection counts them while it builds the bitmap.
+      const PNode& selc = nullable ? C(1) : C(0);
+      const bool counted = selc.enc == ET_SPARSEBOOL && selc.sparse_dn >= 0 && selc.rows == rows;
+      static_assert(kSparseTileRows == kPopcTileRows, "the bitmap step emits the partials of the counting step's tiles");
+      if (counted) {
+        NodeDesc& sd = dnodes[(size_t)selc.sparse_dn];
+        sd.flags |= NF_EMIT_PARTS | (nullable ? 0u : (uint32_t)NF_INVERT_SEL);
+        sd.part_base = d.part_base;
+        sd.aux2 = trows;
+      }
+      const int sel_lvl = selc.ready;
+      const int scan_lvl = counted ? sel_lvl : sel_lvl + 1;
+      const int fin = std::max(lvl, scan_lvl + 1);
       if (nn.fused_select) {
         // the parent scatters for this node: it only counts and scans its ranks
         const uint32_t dn = add_dnode(d);
-        add_step(sel_lvl, K_REDUCE_POPC, 0, dn, div_up32(rows, kPopcTileRows));
-        add_step(sel_lvl + 1, K_SCAN_TILES, 0, dn, 1, true);
+        if (!counted) add_step(sel_lvl, K_REDUCE_POPC, 0, dn, div_up32(rows, kPopcTileRows));
+        add_step(scan_lvl, K_SCAN_TILES, 0, dn, 1, true);
         nn.sel_ref = d.sel;
         nn.sel_part_base = d.part_base;
         nn.sel_total_idx = d.total_idx;
@@ -798,8 +813,8 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       }
       d.self = nn.is_bool ? bits_ref() : mat_ref(es);
       const uint32_t dn = add_dnode(d);
-      add_step(sel_lvl, K_REDUCE_POPC, 0, dn, div_up32(rows, kPopcTileRows));  // each tile emits the partials of kPopcTileRows / trows consumer tiles
-      add_step(sel_lvl + 1, K_SCAN_TILES, 0, dn, 1, true);
+      if (!counted) add_step(sel_lvl, K_REDUCE_POPC, 0, dn, div_up32(rows, kPopcTileRows));  // each tile emits the partials of kPopcTileRows / trows consumer tiles
+      add_step(scan_lvl, K_SCAN_TILES, 0, dn, 1, true);
       if (nn.is_bool) add_step(fin, K_SELECT_BITS, 0, dn, nt);
       else add_step(fin, K_SELECT_SCATTER, es, dn, nt);
       nn.ref = d.self; nn.ready = fin + 1;
@@ -1208,6 +1223,11 @@ nbl_status nbl_plan_upload(nbl_plan* p, void* d_work, void* stream) {
   if (p->blob.empty()) return NBL_OK;
   hipError_t e = hipMemcpyAsync(d_work, p->blob.data(), p->blob.size(), hipMemcpyHostToDevice, static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return hip_fail("hipMemcpyAsync(descriptors)", e);
+  // The control words start at zero here and are not touched by the host again
+  // until nbl_decode_status: the flag word only gathers bits, and the kernels
+  // reset the per-node words they accumulate into, so a decode is launches only.
+  e = hipMemsetAsync(static_cast<uint8_t*>(d_work) + p->ctrl_off, 0, p->ctrl_bytes, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail("hipMemsetAsync(control words)", e);
   return NBL_OK;
 }
 
@@ -1298,8 +1318,7 @@ static nbl_status decode_impl(const nbl_plan* p, nbl_profile* prof, uint32_t ste
     return NBL_ERR_ARGUMENT;
   }
   uint8_t* work = static_cast<uint8_t*>(d_work);
-  hipError_t e = hipMemsetAsync(work + p->ctrl_off, 0, p->ctrl_bytes, static_cast<hipStream_t>(stream));
-  if (e != hipSuccess) return hip_fail("hipMemsetAsync(control words)", e);
+  hipError_t e = hipSuccess;
   KArgs a{};
   a.arena = static_cast<const uint8_t*>(d_arena);
   a.out = static_cast<uint8_t*>(d_out);
@@ -1344,6 +1363,9 @@ nbl_status nbl_decode_status(const nbl_plan* p, const void* d_work, void* stream
   e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
   if (e != hipSuccess) return hip_fail("hipStreamSynchronize", e);
   if (st == 0) return NBL_OK;
+  // reported once: the word gathers bits again from the next decode on
+  e = hipMemsetAsync(const_cast<uint8_t*>(static_cast<const uint8_t*>(d_work)) + p->ctrl_off, 0, 4, static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_fail("hipMemsetAsync(status)", e);
   std::string m = "inconsistent payload:";
   if (st & ST_RLE_SUM_MISMATCH) m += " run lengths do not add up to the row count;";
   if (st & ST_DICT_INDEX_RANGE) m += " dictionary index out of range;";

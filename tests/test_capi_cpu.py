@@ -241,7 +241,10 @@ def test_values_children_resolved_inside_the_rank_scatter():
     assert "k_rle_expand<2>" in got and "k_select_scatter<2>" in got  # narrow rows: two passes
     mc = np.where(rng.random(nn) < 0.9, 7, rng.integers(100, 1000, nn)).astype(np.int64)
     got = names(E.encode_nullable(E.Nullable(data=E.MainlyConstant(), nulls=E.SparseBool()), mc, mask, W.INT64))
-    assert got.count("k_select_scatter<8>") == 1 and "k_reduce_popc" in got  # both nodes count ranks, one scatters
+    # both nodes count ranks, one scatters; SparseBool selections count while they build their bitmaps
+    assert got == ["k_sparse_bits", "k_scan_tiles", "k_select_scatter<8>"]
+    got = names(E.encode_nullable(E.Nullable(data=E.MainlyConstant(is_common=E.Trivial()), nulls=E.SparseBool()), mc, mask, W.INT64))
+    assert got.count("k_select_scatter<8>") == 1 and "k_reduce_popc" in got  # a plain bitmap is counted by a pass of its own
     # nesting goes one deep: of three MainlyConstants the middle one is resolved by the outermost, the innermost scatters itself
     v = np.where(rng.random(n) < 0.8, 1, np.where(rng.random(n) < 0.7, 2, rng.integers(3, 9, n))).astype(np.int32)
     three = E.encode(E.MainlyConstant(other=E.MainlyConstant(other=E.MainlyConstant())), v, W.INT32)
