@@ -96,6 +96,7 @@ enum NodeFlags : uint32_t {
                                // common value, part_base2 / total_idx2 = its scanned rank partials and total
   NF_EMIT_PARTS = 1u << 8,   // K_SPARSE_BITS: the bitmap is the selection of its parent; also write the parent's rank
                              // partials (part_base, aux2 = rows per parent tile; NF_INVERT_SEL: count the zero bits)
+  NF_SPARSE_DENSE = 1u << 9, // K_SPARSE_BITS: tiles of kBitTileRows rows instead of kSparseTileRows
   NF_FRAME_BITS = 1u << 4,   // K_FRAME_UNPACK: FOR (u64 bit offsets, no raw marker) instead of
                              // BlockBitPacking (u32 byte offsets, width 255 = raw block)
 };

@@ -272,9 +272,10 @@ __device__ __forceinline__ void vec_set(Vec16<ES>& x, uint32_t j, typename ElemT
 }
 
 // Store up to 16/ES elements starting at element e0 of `dst`; full vectors as
-// one 16-byte store.
-template <int ES>
-__device__ __forceinline__ void store_vec(typename ElemT<ES>::type* dst, uint64_t e0, uint64_t rows, const Vec16<ES>& x) {
+// one 16-byte store.  Tile-relative callers pass 32-bit indices and get 32-bit
+// compares (e0 + V cannot wrap: a tile has at most kTileBytes elements).
+template <int ES, typename I>
+__device__ __forceinline__ void store_vec(typename ElemT<ES>::type* dst, I e0, I rows, const Vec16<ES>& x) {
   constexpr uint32_t V = 16 / ES;
   if (e0 + V <= rows) {
     // decoded columns are written once and not re-read by this pass: a
@@ -763,14 +764,15 @@ __device__ __forceinline__ void body_reduce_sum(const KArgs& a, const NodeDesc& 
   if (threadIdx.x == 0) a.parts[nd.part_base + tile] = tot;
 }
 
-// Rank partials of kPopcWordsPerThread * kBlock consecutive bitmap words, word
-// (tile * kPopcWordsPerThread + u) * kBlock + threadIdx.x counted in cnt[u]: one
-// partial per consumer tile of `sub` words (32, 64, 128 or 256) to parts[part_base + ..].
+// Rank partials of WPT * kBlock consecutive bitmap words, word
+// (tile * WPT + u) * kBlock + threadIdx.x counted in cnt[u]: one partial per
+// consumer tile of `sub` words (32, 64, 128 or 256) to parts[part_base + ..].
+template <uint32_t WPT>
 __device__ __forceinline__ void emit_rank_partials(const KArgs& a, uint32_t part_base, uint32_t sub, uint64_t rows, uint32_t tile,
-                                                   const uint32_t (&cnt)[kPopcWordsPerThread], uint32_t* tmp) {
+                                                   const uint32_t (&cnt)[WPT], uint32_t* tmp) {
 #pragma unroll
-  for (uint32_t u = 0; u < kPopcWordsPerThread; ++u) {
-    const uint64_t w = ((uint64_t)tile * kPopcWordsPerThread + u) * kBitTileWords + threadIdx.x;
+  for (uint32_t u = 0; u < WPT; ++u) {
+    const uint64_t w = ((uint64_t)tile * WPT + u) * kBitTileWords + threadIdx.x;
     const bool live = w * 64 < rows;
     uint32_t s = cnt[u];
 #pragma unroll
@@ -798,7 +800,7 @@ __device__ __forceinline__ void body_reduce_popc(const KArgs& a, const NodeDesc&
     const uint64_t w = ((uint64_t)tile * kPopcWordsPerThread + u) * kBitTileWords + threadIdx.x;
     cnt[u] = w * 64 < nd.sel.rows ? (uint32_t)__popcll(sel.word(w)) : 0u;
   }
-  emit_rank_partials(a, nd.part_base, (uint32_t)(nd.aux2 >> 6), nd.sel.rows, tile, cnt, reinterpret_cast<uint32_t*>(smem));
+  emit_rank_partials<kPopcWordsPerThread>(a, nd.part_base, (uint32_t)(nd.aux2 >> 6), nd.sel.rows, tile, cnt, reinterpret_cast<uint32_t*>(smem));
 }
 
 // A varint starts at payload byte b when b == 0 or byte b-1 has its high bit
@@ -1131,19 +1133,17 @@ __device__ __forceinline__ void body_rle_expand_bool(const KArgs& a, const NodeD
 // ------------------------------------------------------------- K_SPARSE_BITS
 // SparseBoolEncoding::materializeBoolsAsBits (encodings/SparseBoolEncoding.cpp:121-142):
 // every row is !sparseValue except the listed (ascending) positions.
-__device__ __forceinline__ void body_sparse_bits(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
-  // A tile is 65536 rows (8 KiB of bitmap, four words per thread): the two
-  // searches for the tile's range of positions are a chain of dependent loads
-  // and the output is tiny, so few large tiles beat many small ones.
-  constexpr uint32_t W = kSparseTileWords;
+template <uint32_t W>
+__device__ __forceinline__ void sparse_bits_tile(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
   constexpr uint32_t WPT = W / kBlock;
-  static_assert(W % kBlock == 0 && W * 8 + 8 <= kSmemBytes, "sparse tile geometry");
+  constexpr uint32_t TR = W * 64;  // rows per tile
+  static_assert(W % kBlock == 0 && W * 8 + 8 <= kSmemBytes && kBlock == kBitTileWords, "sparse tile geometry");
   uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem);
   uint32_t* s_k = reinterpret_cast<uint32_t*>(smem + W * 8);
   const uint64_t rows = nd.rows;
   const uint32_t K = nd.c0.rows;
-  const uint64_t p0 = (uint64_t)tile * kSparseTileRows;
-  const uint64_t p1 = p0 + kSparseTileRows < rows ? p0 + kSparseTileRows : rows;
+  const uint64_t p0 = (uint64_t)tile * TR;
+  const uint64_t p1 = p0 + TR < rows ? p0 + TR : rows;
   uint64_t* dst = reinterpret_cast<uint64_t*>(a.work + nd.self.off);
   with_reader<4>(nd.c0, a, [&](auto rd) {
     if (wave_id() == 0) {
@@ -1160,16 +1160,17 @@ __device__ __forceinline__ void body_sparse_bits(const KArgs& a, const NodeDesc&
     __syncthreads();
     const uint32_t lo = s_k[0], hi = s_k[1];
     uint32_t* bits32 = reinterpret_cast<uint32_t*>(s_bits);
-    // four positions per thread in flight per round
-    for (uint32_t j0 = lo + threadIdx.x; j0 < hi; j0 += 4 * kBlock) {
-      uint32_t pos[4];
+    // eight positions per thread in flight per round: every round waits for its loads
+    constexpr uint32_t PPT = 8;
+    for (uint32_t j0 = lo + threadIdx.x; j0 < hi; j0 += PPT * kBlock) {
+      uint32_t pos[PPT];
 #pragma unroll
-      for (uint32_t u = 0; u < 4; ++u) {
+      for (uint32_t u = 0; u < PPT; ++u) {
         const uint32_t j = j0 + u * kBlock;
         pos[u] = rd.get(j < hi ? j : hi - 1);
       }
 #pragma unroll
-      for (uint32_t u = 0; u < 4; ++u) {
+      for (uint32_t u = 0; u < PPT; ++u) {
         const uint32_t j = j0 + u * kBlock;
         if (j < hi && pos[u] >= p0 && pos[u] < p1) {
           const uint32_t q = (uint32_t)(pos[u] - p0);
@@ -1182,7 +1183,6 @@ __device__ __forceinline__ void body_sparse_bits(const KArgs& a, const NodeDesc&
   // The parent that selects by this bitmap takes its rank partials from here
   // (NF_EMIT_PARTS: part_base / aux2 are the parent's, NF_INVERT_SEL = it
   // selects the zero bits), so no counting pass reads the bitmap back.
-  static_assert(WPT == kPopcWordsPerThread && kBlock == kBitTileWords, "same word layout as the counting pass");
   const bool emit = (nd.flags & NF_EMIT_PARTS) != 0, zeros = (nd.flags & NF_INVERT_SEL) != 0;
   uint32_t cnt[WPT];
 #pragma unroll
@@ -1198,7 +1198,18 @@ __device__ __forceinline__ void body_sparse_bits(const KArgs& a, const NodeDesc&
       cnt[u] = (uint32_t)__popcll(zeros ? ~v & m : v);
     }
   }
-  if (emit) emit_rank_partials(a, nd.part_base, (uint32_t)(nd.aux2 >> 6), rows, tile, cnt, reinterpret_cast<uint32_t*>(smem));
+  if (emit) emit_rank_partials<WPT>(a, nd.part_base, (uint32_t)(nd.aux2 >> 6), rows, tile, cnt, reinterpret_cast<uint32_t*>(smem));
+}
+
+__device__ __forceinline__ void body_sparse_bits(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
+  // A tile is 65536 rows (8 KiB of bitmap, four words per thread): the two
+  // searches for the tile's range of positions are a chain of dependent loads
+  // and the output is tiny, so few large tiles beat many small ones -- unless
+  // the column is dense (NF_SPARSE_DENSE, the planner's choice): then a tile's
+  // positions take several rounds of loads, and 16384-row tiles put four times
+  // the workgroups on them.
+  if (nd.flags & NF_SPARSE_DENSE) sparse_bits_tile<kBitTileWords>(a, nd, tile, smem);
+  else sparse_bits_tile<kSparseTileWords>(a, nd, tile, smem);
 }
 
 // ---------------------------------------------------------- K_SELECT_SCATTER
@@ -1461,10 +1472,10 @@ __device__ __forceinline__ void select_nested(const KArgs& a, const NodeDesc& nd
           if ((sel >> j) & 1u) {
             v = fill2;
             if (ib & 1u) {
-              uint32_t rc = r2 < last2 ? r2 : last2;
-              rc = rc < ob ? ob : rc;
-              rc = rc < oe ? rc : (oe ? oe - 1 : 0);
-              v = cnt2 ? vals.at(rc - ob) : (T)0;
+              // inner ranks come from the same bitmap words as [ob, oe), so r2 lies inside;
+              // one unsigned clamp keeps a damaged input inside the stage all the same
+              const uint32_t k = r2 - ob;
+              v = cnt2 ? vals.at(k < cnt2 ? k : cnt2 - 1) : (T)0;
               ++r2;
             }
             ib >>= 1;

@@ -108,6 +108,8 @@ struct PNode {
   int ready = 0;             // level after which `ref` is valid
 };
 
+constexpr size_t kDenseSparseMaxChunks = 512;
+
 struct Step {
   int level;
   uint32_t kernel;
@@ -699,8 +701,16 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       d.c0 = C(0).ref;
       d.rows = rows;
       if (nn.flag) d.flags |= NF_SPARSE_VALUE;
+      // more than 2048 positions per 65536 rows: a large tile would need several
+      // rounds of position loads, so the column is cut into four times the tiles --
+      // in batches of few chunks, whose bitmap tiles do not fill the chip's
+      // workgroup slots and wait for the slowest tile.  A batch of thousands of
+      // columns is bound by the fixed cost per tile instead (measured: +16%
+      // on the bitmap level of a 5,000-column stripe with the small tiles).
+      const bool dense = (uint64_t)C(0).rows * 32 > rows && layouts.size() <= kDenseSparseMaxChunks;
+      if (dense) d.flags |= NF_SPARSE_DENSE;
       const uint32_t dn = add_dnode(d);
-      add_step(lvl, K_SPARSE_BITS, 0, dn, div_up32(rows, kSparseTileRows));
+      add_step(lvl, K_SPARSE_BITS, 0, dn, div_up32(rows, dense ? kBitTileRows : kSparseTileRows));
       if (rows > 0) nn.sparse_dn = (int)dn;
       nn.ref = d.self; nn.ready = lvl + 1;
       break;
@@ -788,7 +798,6 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       // A SparseBool selection counts them while it builds the bitmap.
       const PNode& selc = nullable ? C(1) : C(0);
       const bool counted = selc.enc == ET_SPARSEBOOL && selc.sparse_dn >= 0 && selc.rows == rows;
-      static_assert(kSparseTileRows == kPopcTileRows, "the bitmap step emits the partials of the counting step's tiles");
       if (counted) {
         NodeDesc& sd = dnodes[(size_t)selc.sparse_dn];
         sd.flags |= NF_EMIT_PARTS | (nullable ? 0u : (uint32_t)NF_INVERT_SEL);

@@ -251,6 +251,24 @@ def test_values_children_resolved_inside_the_rank_scatter():
     assert names(three).count("k_select_scatter<4>") == 2
 
 
+def test_dense_sparse_bool_gets_smaller_bitmap_tiles():
+    """A SparseBool whose listed positions are more than 1/32 of its rows is cut
+    into 16384-row tiles (a tile's positions are loaded in rounds), a sparser
+    one into 65536-row tiles (the search for a tile's range dominates)."""
+    n = 200_000
+    rng = np.random.default_rng(8)
+
+    def sparse_tiles(frac):
+        b = rng.random(n) < frac
+        p = Plan.from_encodings([E.encode(E.SparseBool(), b, W.BOOL)], per_kernel=True)
+        t = [l[2] for l in p.launches() if l[0] == "k_sparse_bits"]
+        p.close()
+        return t
+
+    assert sparse_tiles(0.01) == [-(-n // 65536)]
+    assert sparse_tiles(0.2) == [-(-n // 16384)]
+
+
 def _rle_bytes(dtype, rows, lengths, values, varint_rows=False):
     lens = E.encode(E.Trivial(), np.asarray(lengths, dtype=np.uint32), W.UINT32, varint_rows)
     vals = E.encode(E.Trivial(), np.asarray(values).astype(W.physical_dtype(dtype)), dtype, varint_rows)
