@@ -147,3 +147,35 @@ def test_rle_without_rows_over_non_empty_run_lengths(gpu, oracle, varint_rows):
     neighbour = E.encode(E.RLE(), np.repeat(np.arange(50, dtype=np.int64), 40), W.INT64, varint_rows)
     res = check_parity(oracle, empty_rle_cases(varint_rows) + [neighbour], varint_rows)
     assert [r.rows for r in res] == [0, 3000, 0, 2000]
+
+
+def test_status_gathers_over_decodes_and_clears_when_reported(gpu, oracle):
+    """The flag word lives in the work buffer: it is zeroed by the upload, every
+    decode can only add bits, and the call that reports them clears them.  A
+    damaged batch therefore reports once per decode (or series of decodes), a
+    later report without a decode in between is clean, and the zero-length-run
+    flag of an RLE node is rebuilt by every decode (its scan resets it)."""
+    bad = _rle(W.INT64, 5000, [1000, 1000, 1000], [1, 2, 3])
+    plan = Plan.from_encodings([bad])
+    dec = BatchDecoder(plan)
+    dec.stage()
+    dec.decode()
+    dec.decode()
+    with pytest.raises(capi.NimbleError, match="run lengths"):
+        dec.status()
+    dec.status()  # reported and cleared, nothing decoded since
+    dec.decode()
+    with pytest.raises(capi.NimbleError, match="run lengths"):
+        dec.status()
+    plan.close()
+    # zero-length runs: the same decoder decodes twice, both passes match the oracle
+    enc = _rle(W.INT32, 12, [3, 0, 0, 4, 0, 5, 0], [10, 11, 12, 13, 14, 15, 16])
+    plan = Plan.from_encodings([enc])
+    dec = BatchDecoder(plan)
+    dec.stage()
+    for _ in range(2):
+        dec.decode()
+        dec.status()
+        got = dec.fetch()[0]
+        assert np.asarray(got.values).view(np.int32).tolist() == [10] * 3 + [13] * 4 + [15] * 5
+    plan.close()
