@@ -97,6 +97,7 @@ enum NodeFlags : uint32_t {
   NF_EMIT_PARTS = 1u << 8,   // K_SPARSE_BITS: the bitmap is the selection of its parent; also write the parent's rank
                              // partials (part_base, aux2 = rows per parent tile; NF_INVERT_SEL: count the zero bits)
   NF_SPARSE_DENSE = 1u << 9, // K_SPARSE_BITS: tiles of kBitTileRows rows instead of kSparseTileRows
+  NF_BOOL_BYTES = 1u << 10,  // K_RLE_EXPAND_BOOL: the node is a chunk's root: self = its values in out, one byte per row
   NF_FRAME_BITS = 1u << 4,   // K_FRAME_UNPACK: FOR (u64 bit offsets, no raw marker) instead of
                              // BlockBitPacking (u32 byte offsets, width 255 = raw block)
 };

@@ -744,6 +744,25 @@ __device__ __forceinline__ void body_bits_to_bytes(const KArgs& a, const NodeDes
   }
 }
 
+// The kBitTileWords bitmap words of one tile, held in LDS, written as one byte
+// per row at rows [start, start + kBitTileRows) of a bool column (start is a
+// multiple of the tile): what body_bits_to_bytes does from a bitmap in memory,
+// for producers that emit a root bool column themselves (NF_BOOL_BYTES).
+__device__ __forceinline__ void tile_words_to_bytes(const uint64_t* s_words, uint8_t* dst, uint64_t start, uint64_t rows) {
+#pragma unroll
+  for (uint32_t it = 0; it < 4; ++it) {
+    const uint32_t r0 = (it * kBlock + threadIdx.x) * 16;
+    const uint64_t e0 = start + r0;
+    if (e0 >= rows) break;
+    const uint32_t b16 = (uint32_t)(s_words[r0 >> 6] >> (r0 & 63)) & 0xFFFFu;
+    Vec16<1> x;
+    const uint64_t lo = spread8(b16), hi = spread8(b16 >> 8);
+    x.q.x = (uint32_t)lo; x.q.y = (uint32_t)(lo >> 32);
+    x.q.z = (uint32_t)hi; x.q.w = (uint32_t)(hi >> 32);
+    store_vec<1>(dst, e0, rows, x);
+  }
+}
+
 // -------------------------------------------------------------- tile reduces
 __device__ __forceinline__ void body_reduce_sum(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
   uint32_t* tmp = reinterpret_cast<uint32_t*>(smem);
@@ -1069,13 +1088,23 @@ __device__ __forceinline__ void body_rle_expand_bool(const KArgs& a, const NodeD
   const uint32_t R = nd.c0.rows;
   const uint64_t p0 = (uint64_t)tile * kBitTileRows;
   const uint64_t p1 = p0 + kBitTileRows < rows ? p0 + kBitTileRows : rows;
+  // a root column is written as bytes straight away (NF_BOOL_BYTES: self = the
+  // chunk's values in out), anything else as bitmap words in work
+  const bool bytes = (nd.flags & NF_BOOL_BYTES) != 0;
   uint64_t* dst = reinterpret_cast<uint64_t*>(a.work + nd.self.off);
+  uint8_t* dst_bytes = a.out + nd.self.off;
   const uint32_t* ends = reinterpret_cast<const uint32_t*>(a.work + nd.aux_off);
   const uint64_t firstmask = (nd.flags & NF_FIRST_TRUE) ? ~0ull : 0ull;
   const uint64_t w = (uint64_t)tile * W + threadIdx.x;  // output word of this thread
   if (tile == 0 && threadIdx.x == 0 && sload32(a.totals + nd.total_idx) != nd.rows) atomicOr(a.status, ST_RLE_SUM_MISMATCH);
   if (R == 0) {
-    if (w * 64 < rows) dst[w] = 0;
+    if (bytes) {
+      s_bits[threadIdx.x] = 0;
+      __syncthreads();
+      tile_words_to_bytes(s_bits, dst_bytes, p0, rows);
+    } else if (w * 64 < rows) {
+      dst[w] = 0;
+    }
     return;
   }
   const bool slow = sload32(a.totals + nd.total_idx + 1) != 0;
@@ -1109,8 +1138,12 @@ __device__ __forceinline__ void body_rle_expand_bool(const KArgs& a, const NodeD
     uint64_t odd = prefix_xor64(word);
     if ((k0 + ex) & 1u) odd = ~odd;
     uint64_t v = firstmask ^ odd;
-    if (w * 64 < rows) {
-      if (w * 64 + 64 > rows) v &= wmask((uint32_t)(rows - w * 64));
+    if (w * 64 >= rows) v = 0;
+    else if (w * 64 + 64 > rows) v &= wmask((uint32_t)(rows - w * 64));
+    if (bytes) {
+      __syncthreads();  // every thread has read its boundary word
+      s_bits[threadIdx.x] = v;
+    } else if (w * 64 < rows) {
       dst[w] = v;
     }
   } else {
@@ -1125,8 +1158,15 @@ __device__ __forceinline__ void body_rle_expand_bool(const KArgs& a, const NodeD
         bit = (((k & 1u) ? ~firstmask : firstmask) & 1ull) != 0;
       }
       const uint64_t v = __ballot(bit);
-      if (lane_id() == 0) dst[ww] = v;
+      if (lane_id() == 0) {
+        if (bytes) s_bits[i] = v;
+        else dst[ww] = v;
+      }
     }
+  }
+  if (bytes) {
+    __syncthreads();
+    tile_words_to_bytes(s_bits, dst_bytes, p0, rows);
   }
 }
 

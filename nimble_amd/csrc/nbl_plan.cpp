@@ -671,7 +671,12 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       d.aux2 = out_tile_rows;
       d.aux_off = alloc_work((((uint64_t)R + 3) & ~3ull) * 4 + (uint64_t)div_up32(rows, out_tile_rows) * 4);
       if (nn.is_bool) {
-        d.self = bits_ref();
+        if (root) {  // the expansion writes the chunk's bytes itself: no bitmap, no separate bit -> byte step
+          d.self = *root_dst; d.self.rows = rows; d.self.es = 1;
+          d.flags |= NF_BOOL_BYTES;
+        } else {
+          d.self = bits_ref();
+        }
         if (nn.flag) d.flags |= NF_FIRST_TRUE;
       } else {
         if (!nn.fused_runs) d.self = mat_ref(es);
@@ -869,7 +874,9 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
   }
   if (root) {
     PNode& r = nodes[idx];
-    if (r.is_bool) {  // bitmap (or constant) -> one byte per row
+    if (r.is_bool && r.ref.kind == COL_MAT_OUT) {
+      // an RLE<bool> root has written its bytes already
+    } else if (r.is_bool) {  // bitmap (or constant) -> one byte per row
       NodeDesc d{};
       d.self = *root_dst; d.self.rows = rows; d.self.es = 1;
       d.c0 = r.ref; d.rows = rows;

@@ -251,6 +251,20 @@ def test_values_children_resolved_inside_the_rank_scatter():
     assert names(three).count("k_select_scatter<4>") == 2
 
 
+def test_bool_rle_root_expands_to_bytes_without_a_bitmap_step():
+    """An RLE<bool> that is a chunk's root writes one byte per row from its
+    expansion; under a Nullable it stays a bitmap for the select step."""
+    b = np.repeat(np.arange(500) & 1, 77).astype(bool)
+    p = Plan.from_encodings([E.encode(E.RLE(), b, W.BOOL)], per_kernel=True)
+    assert [l[0] for l in p.launches()] == ["k_reduce_sum", "k_scan_tiles", "k_rle_ends", "k_rle_expand_bool"]
+    p.close()
+    mask = np.random.default_rng(9).random(60_000) < 0.5
+    enc = E.encode_nullable(E.Nullable(data=E.RLE(), nulls=E.Trivial()), b[: int(mask.sum())], mask, W.BOOL)
+    p = Plan.from_encodings([enc], per_kernel=True)
+    assert [l[0] for l in p.launches()][-2:] == ["k_select_bits", "k_bits_to_bytes"]
+    p.close()
+
+
 def test_dense_sparse_bool_gets_smaller_bitmap_tiles():
     """A SparseBool whose listed positions are more than 1/32 of its rows is cut
     into 16384-row tiles (a tile's positions are loaded in rounds), a sparser

@@ -179,3 +179,24 @@ def test_status_gathers_over_decodes_and_clears_when_reported(gpu, oracle):
         got = dec.fetch()[0]
         assert np.asarray(got.values).view(np.int32).tolist() == [10] * 3 + [13] * 4 + [15] * 5
     plan.close()
+
+
+def test_bool_rle_root_with_zero_length_runs(gpu, oracle):
+    """RLE<bool> as a chunk's root writes its bytes itself; zero-length runs (which
+    flip the value without a row) take the per-row search, several tiles long."""
+    rng = np.random.default_rng(11)
+    encs = []
+    for rows in (12, 16384, 50_000):
+        lengths = []
+        left = rows
+        while left:
+            if rng.random() < 0.2:
+                lengths.append(0)
+                continue
+            n = int(min(left, rng.integers(1, 400)))
+            lengths.append(n)
+            left -= n
+        for first in (0, 1):
+            lens = E.encode(E.Trivial(), np.asarray(lengths, dtype=np.uint32), W.UINT32)
+            encs.append(E.prefix(W.RLE, W.BOOL, rows) + struct.pack("<I", len(lens)) + lens + bytes([first]))
+    check_parity(oracle, encs)
