@@ -20,6 +20,34 @@
 
 namespace nbl {
 
+// Development aid (-DNBL_PHASE_TIMING): thread 0 of every rank-scatter tile adds
+// the cycles between marks to g_phase[]; a mark first waits for everything the
+// wave has outstanding, so the slots hold arrival times of a tile's dependent
+// loads.  Never part of a product build.
+#ifdef NBL_PHASE_TIMING
+constexpr uint32_t kPhaseTiles = 1u << 18;     // one record of 8 cycle counts per tile, no atomics (they would serialise the launch)
+__device__ uint32_t g_phase[kPhaseTiles * 8];
+constexpr uint32_t kPhaseBytes = 16;  // thread 0 keeps the time of its last mark behind the workgroup's LDS
+#define NBL_PHASE_BEGIN(smem, size)                                                                        \
+  do {                                                                                                     \
+    if (threadIdx.x == 0) *reinterpret_cast<unsigned long long*>((smem) + (size)) = __builtin_readcyclecounter(); \
+  } while (0)
+#define NBL_PHASE(smem, size, i)                                                           \
+  do {                                                                                     \
+    __builtin_amdgcn_s_waitcnt(0);                                                         \
+    if (threadIdx.x == 0) {                                                                \
+      unsigned long long* tp_ = reinterpret_cast<unsigned long long*>((smem) + (size));    \
+      const unsigned long long t_ = __builtin_readcyclecounter();                          \
+      g_phase[(blockIdx.x & (kPhaseTiles - 1)) * 8 + (i)] = (uint32_t)(t_ - *tp_);         \
+      *tp_ = t_;                                                                           \
+    }                                                                                      \
+  } while (0)
+#else
+constexpr uint32_t kPhaseBytes = 0;
+#define NBL_PHASE_BEGIN(smem, size) do {} while (0)
+#define NBL_PHASE(smem, size, i) do {} while (0)
+#endif
+
 // ------------------------------------------------------------------ helpers
 __device__ __forceinline__ uint64_t ldu64(const uint8_t* p) {
   uint64_t v;
@@ -460,6 +488,15 @@ struct Reader {
     __device__ __forceinline__ T at(uint32_t rel) const {
       if constexpr (RK == RK_CONST) {
         return r.base;
+      } else if constexpr (RK == RK_PTR && CES >= 4) {
+        // whole-dword elements: every element sits at the same (wave uniform) bit
+        // shift inside its dwords, so the address is one shift-add and the two
+        // or three dwords come from one LDS instruction
+        const uint32_t S = bit0 & 31u;
+        const uint32_t* q = s32 + (bit0 >> 5) + rel * (uint32_t)(CES / 4);
+        const uint32_t lo = __builtin_amdgcn_alignbit(q[1], q[0], S);
+        if constexpr (CES == 8) return (T)((((uint64_t)__builtin_amdgcn_alignbit(q[2], q[1], S) << 32) | lo) + r.base);
+        else return (T)((T)lo + r.base);
       } else {
         const uint32_t lb = bit0 + rel * (RK == RK_PTR ? 8u * CES : r.w);
         const uint32_t d0 = lb >> 5, S = lb & 31u;
@@ -524,9 +561,12 @@ __device__ __forceinline__ void with_reader(const ColRef& c, const KArgs& a, F&&
 
 // LDS of one workgroup, shared by every body (the fused launch runs them all):
 // [0, kStageBytes) staged bytes or values of a tile (16 KiB + alignment slack),
-// then 2 KiB of bitmap words, 1 KiB of prefix counts, 64 bytes of scratch.
+// then 2 KiB of bitmap words, 1 KiB of prefix counts, 64 bytes of scratch, 256
+// bytes of bit-deposit table.
 constexpr uint32_t kStageBytes = kTileBytes + 64;
-constexpr uint32_t kSmemBytes = kStageBytes + 2048 + 1024 + 64;
+constexpr uint32_t kSmemBytes = kStageBytes + 2048 + 1024 + 64 + 256;
+constexpr uint32_t kDepositOff = kStageBytes + 2048 + 1024 + 64;  // 256-byte table of the nested rank scatter
+static_assert(kSmemBytes * 8 <= 160 * 1024, "eight workgroups per CU share the LDS");
 
 // =========================================================== tile bodies
 // Every body processes ONE tile of one node.  They are instantiated twice: in
@@ -1254,22 +1294,57 @@ __device__ __forceinline__ void body_sparse_bits(const KArgs& a, const NodeDesc&
 
 // ---------------------------------------------------------- K_SELECT_SCATTER
 // In-tile exclusive scan of the popcounts of the W bitmap words of a tile
-// (thread i < W holds word i); leaves words and prefixes in LDS.  Up to 64
-// words fit one wave, which then needs no barrier of its own; the caller
-// synchronises before reading s_bits / s_pref.
+// (thread i < W holds word i).  Up to 64 words fit one wave, which then needs
+// no barrier of its own.  The prefixes are kept per 32-bit half of every word, as 16-bit
+// counts (a tile has at most 16384 rows): a row then finds its rank with one
+// dword of bits, one prefix and a 32-bit popcount, whose bit offset inside the
+// dword is the same in every pass of a thread over the tile.  Thread i < W
+// holds word i; s_bits receives the words (read back as dwords), s_pref the
+// 2 W prefixes.  The caller synchronises before reading either.
 template <uint32_t W>
-__device__ __forceinline__ void tile_rank_scan(uint64_t word, uint64_t* s_bits, uint32_t* s_pref, uint32_t* tmp) {
+__device__ __forceinline__ void tile_rank_scan32(uint64_t word, uint64_t* s_bits, uint16_t* s_pref, uint32_t* tmp) {
+  const uint32_t c0 = (uint32_t)__popc((uint32_t)word), c1 = (uint32_t)__popc((uint32_t)(word >> 32));
   if constexpr (W <= 64) {
     if (threadIdx.x < 64) {
-      const uint32_t c = (uint32_t)__popcll(word);
-      const uint32_t incl = wave_incl_scan(c);
-      if (threadIdx.x < W) { s_bits[threadIdx.x] = word; s_pref[threadIdx.x] = incl - c; }
+      const uint32_t ex = wave_incl_scan(c0 + c1) - c0 - c1;
+      if (threadIdx.x < W) {
+        s_bits[threadIdx.x] = word;
+        reinterpret_cast<uint32_t*>(s_pref)[threadIdx.x] = ex | ((ex + c0) << 16);
+      }
     }
   } else {
     uint32_t total;
-    const uint32_t ex = block_excl_scan((uint32_t)__popcll(word), tmp, total);
-    if (threadIdx.x < W) { s_bits[threadIdx.x] = word; s_pref[threadIdx.x] = ex; }
+    const uint32_t ex = block_excl_scan(c0 + c1, tmp, total);
+    if (threadIdx.x < W) {
+      s_bits[threadIdx.x] = word;
+      reinterpret_cast<uint32_t*>(s_pref)[threadIdx.x] = ex | ((ex + c0) << 16);
+    }
   }
+}
+// Rows q0 .. q0 + V - 1 of the tile (q0 a multiple of V, V <= 16): `bits` = their
+// selection bits, `r` = the rank of row q0 (set bits of the tile in front of it).
+template <uint32_t V>
+__device__ __forceinline__ void vector_ranks(const uint32_t* bits32, const uint16_t* pref16, uint32_t q0, uint32_t& r, uint32_t& bits) {
+  const uint32_t d = q0 >> 5, b = q0 & 31u;
+  const uint32_t w = bits32[d];
+  r = (uint32_t)pref16[d] + (uint32_t)__popc(w & ((1u << b) - 1u));
+  bits = (w >> b) & ((1u << V) - 1u);
+}
+// v where bit j of `bits` is set, otherwise f -- without a compare: the bit is
+// stretched into a mask (one bit-field extract) and the mask picks (one bit-field insert)
+template <typename T>
+__device__ __forceinline__ T pick(uint32_t bits, uint32_t j, T v, T f) {
+  const T m = (T)(int64_t)(int32_t)__builtin_amdgcn_sbfe(bits, j, 1u);  // 0 or all ones (the builtin's result is unsigned)
+  return (T)((v & m) | (f & ~m));
+}
+// 16-byte store of the vector at element e0 of a tile of `rows` elements whose
+// destination is a column of its own in `work` or `out`: those start on 256-byte
+// boundaries and own the bytes up to the next one, so the vector holding the
+// column's last row is stored whole (its rows past the end carry the fill)
+// instead of element by element under a second layer of branches.
+template <int ES>
+__device__ __forceinline__ void store_vec_padded(typename ElemT<ES>::type* dst, uint32_t e0, uint32_t rows, const Vec16<ES>& x) {
+  if (e0 < rows) __builtin_nontemporal_store(x.q, reinterpret_cast<u32x4*>(dst + e0));
 }
 
 // Rank scatter whose values child is an RLE (Nullable{RLE{..}}): the runs are
@@ -1407,11 +1482,11 @@ __device__ __forceinline__ void select_nested(const KArgs& a, const NodeDesc& nd
   constexpr uint32_t V = 16 / ES;
   constexpr uint32_t TE = select_tile_rows(ES);
   constexpr uint32_t W = TE / 64;
-  static_assert(W <= 64 && 3 * W <= 256, "outer words, then up to two inner tiles of words, share the bitmap area");
+  static_assert(W <= 64 && 3 * W <= 256 && V <= 4, "outer words, then up to two inner tiles of words, share the bitmap area");
   uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem + kStageBytes);
-  uint32_t* s_pref = reinterpret_cast<uint32_t*>(smem + kStageBytes + 2048);
+  uint16_t* s_pref = reinterpret_cast<uint16_t*>(smem + kStageBytes + 2048);
+  uint8_t* s_dep = smem + kDepositOff;
   const T fill2 = (T)nd.aux3;
-  const uint32_t rows1 = nd.c0.rows;            // rows of the inner node (>= base + n, by the caller's clamp)
   const uint32_t nothers = nd.c1.rows;
   // inner tiles j0..j1 hold the outer ranks of this tile (n <= TE: at most two of them)
   const uint32_t j0 = base / TE, j1 = (base + n - 1) / TE;
@@ -1420,6 +1495,7 @@ __device__ __forceinline__ void select_nested(const KArgs& a, const NodeDesc& nd
   ob = ob < nothers ? ob : nothers;                         // scan results of damaged input are clamped, never followed
   oe = oe < nothers ? oe : nothers;
   oe = oe < ob ? ob : oe;
+  NBL_PHASE(smem, kSmemBytes, 2);  // the outer word (requested by the caller) and the inner partials
   const uint32_t cnt2 = oe - ob;
   const bool staged = rd.fits(cnt2);
   const uint32_t w0 = j0 * W;                                // first inner word needed
@@ -1439,37 +1515,60 @@ __device__ __forceinline__ void select_nested(const KArgs& a, const NodeDesc& nd
   regs.nvec = 0;
   uint32_t bit0 = 0;
   if (staged && cnt2) bit0 = rd.stage_begin(ob, cnt2, regs);
+  NBL_PHASE(smem, kSmemBytes, 3);  // inner words and staged values (this wave's share)
+  // Deposit table: entry (inner bits << V | outer bits) spreads the low inner
+  // bits over the set positions of the outer bits -- which of a vector's V rows
+  // take an other value.  Its 4^V entries cost each thread a handful of
+  // operations once, against a serial walk over the rows of every vector.
+  if (threadIdx.x < (1u << (2 * V))) {
+    const uint32_t sel = threadIdx.x & ((1u << V) - 1u);
+    uint32_t ib = threadIdx.x >> V, e = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < V; ++j) {
+      const uint32_t sj = (sel >> j) & 1u;
+      e |= (sj & ib) << j;
+      ib >>= sj;
+    }
+    s_dep[threadIdx.x] = (uint8_t)e;
+  }
   if (threadIdx.x < 64) {
-    const uint32_t c = (uint32_t)__popcll(word);
-    const uint32_t incl = wave_incl_scan(c);
-    if (threadIdx.x < W) { s_bits[threadIdx.x] = word; s_pref[threadIdx.x] = incl - c; }
+    tile_rank_scan32<W>(word, s_bits, s_pref, nullptr);
   } else if (threadIdx.x < 128) {
-    const uint32_t c0 = (uint32_t)__popcll(iw0), c1 = (uint32_t)__popcll(iw1);
-    const uint32_t i0 = wave_incl_scan(c0);
+    // inner ranks relative to inner row j0 * TE, i.e. to other value `ob`
+    const uint32_t a0 = (uint32_t)__popc((uint32_t)iw0), a1 = (uint32_t)__popc((uint32_t)(iw0 >> 32));
+    const uint32_t b0 = (uint32_t)__popc((uint32_t)iw1), b1 = (uint32_t)__popc((uint32_t)(iw1 >> 32));
+    const uint32_t i0 = wave_incl_scan(a0 + a1);
     const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)i0, 63);
-    const uint32_t i1 = wave_incl_scan(c1);
-    if (l < nw) { s_bits[W + l] = iw0; s_pref[W + l] = ob + i0 - c0; }
-    if (l + 64 < nw) { s_bits[W + 64 + l] = iw1; s_pref[W + 64 + l] = ob + t0 + i1 - c1; }
+    const uint32_t i1 = wave_incl_scan(b0 + b1);
+    uint32_t* pref2 = reinterpret_cast<uint32_t*>(s_pref + 2 * W);
+    const uint32_t e0 = i0 - a0 - a1, e1 = t0 + i1 - b0 - b1;
+    // every lane writes: words past nw are zero, and the window of the last row reads one dword past its own
+    s_bits[W + l] = iw0; pref2[l] = e0 | ((e0 + a0) << 16);
+    s_bits[W + 64 + l] = iw1; pref2[64 + l] = e1 | ((e1 + b0) << 16);
   }
   const auto vals = rd.stage_end(regs, bit0, smem);  // regs.nvec == 0 when nothing was staged
+  NBL_PHASE(smem, kSmemBytes, 4);  // scans and LDS writes
   __syncthreads();
-  const uint32_t last1 = base + n - 1;                // last inner row this tile may ask for (< rows1)
+  NBL_PHASE(smem, kSmemBytes, 5);  // barrier
+  const uint32_t* ob32 = reinterpret_cast<const uint32_t*>(s_bits);       // the outer words as dwords
+  const uint32_t* ib32 = reinterpret_cast<const uint32_t*>(s_bits + W);   // the inner words as dwords, from word w0
+  const uint16_t* ipref = s_pref + 2 * W;
+  const uint32_t xoff = base - w0 * 64;               // inner row of outer rank 0, relative to the first inner word held
+  const uint32_t xlast = xoff + n - 1;                // last inner row this tile may ask for
   const uint32_t last2 = nothers ? nothers - 1 : 0;
-  const uint32_t* ib32 = reinterpret_cast<const uint32_t*>(s_bits + W);  // the inner words as dwords
   if (!staged) {
     // more other values than the stage holds (a dense inner selection): row by row from global memory
 #pragma unroll 1
     for (uint32_t q = threadIdx.x; q < tile_rows; q += kBlock) {
-      const uint64_t wd = s_bits[q >> 6];
+      const uint32_t wd = ob32[q >> 5];
       T v = fill;
-      if ((wd >> (q & 63)) & 1ull) {
-        uint32_t x = base + s_pref[q >> 6] + (uint32_t)__popcll(wd & ((1ull << (q & 63)) - 1ull));
-        x = x < last1 ? x : last1;
-        const uint32_t wi = W + (x >> 6) - w0;
-        const uint64_t wd2 = s_bits[wi];
+      if ((wd >> (q & 31)) & 1u) {
+        uint32_t x = xoff + s_pref[q >> 5] + (uint32_t)__popc(wd & ((1u << (q & 31)) - 1u));
+        x = x < xlast ? x : xlast;
+        const uint32_t wd2 = ib32[x >> 5];
         v = fill2;
-        if (((wd2 >> (x & 63)) & 1ull) && nothers) {
-          const uint32_t r2 = s_pref[wi] + (uint32_t)__popcll(wd2 & ((1ull << (x & 63)) - 1ull));
+        if (((wd2 >> (x & 31)) & 1u) && nothers) {
+          const uint32_t r2 = ob + ipref[x >> 5] + (uint32_t)__popc(wd2 & ((1u << (x & 31)) - 1u));
           v = rd.get(r2 < last2 ? r2 : last2);
         }
       }
@@ -1477,56 +1576,49 @@ __device__ __forceinline__ void select_nested(const KArgs& a, const NodeDesc& nd
     }
     return;
   }
-  // One 16-byte vector of rows at a time: its selected rows are consecutive
-  // inner rows x, x + 1, ..., so their inner bits are one short window of the
-  // inner bitmap.  Mostly that window is empty (the common value everywhere)
-  // and the vector needs no rank at all.
+  // One 16-byte vector of rows at a time, without a branch inside the wave:
+  // its selected rows are consecutive inner rows x, x + 1, ..., so their inner
+  // bits are one short window of the inner bitmap; the deposit table turns
+  // window and outer bits into the rows that take an other value, and row j's
+  // value is the one at inner rank r2 + (such rows in front of j).
 #pragma unroll
   for (uint32_t it = 0; it < 4; ++it) {
     const uint32_t q0 = (it * kBlock + threadIdx.x) * V;
-    if (q0 >= tile_rows) break;
-    const uint64_t wd = s_bits[q0 >> 6];
-    const uint32_t b = q0 & 63;
-    const uint32_t sel = (uint32_t)(wd >> b) & ((1u << V) - 1u);  // outer bits of the V rows
+    uint32_t r, sel;
+    vector_ranks<V>(ob32, s_pref, q0, r, sel);
+    uint32_t x = xoff + r;
+    x = x < xlast ? x : xlast;
+    const uint32_t d = x >> 5, sh = x & 31u;
+    const uint32_t lo = ib32[d], hi = ib32[d + 1];
+    const uint32_t ib = __builtin_amdgcn_alignbit(hi, lo, sh) & ((1u << V) - 1u);  // inner bits of rows x, x + 1, ...
+    uint32_t e = s_dep[(ib << V) | sel];
+    e = cnt2 ? e : 0u;
     Vec16<ES> o;
-    if (sel == 0) {
+    o.q = make_u32x4(0, 0, 0, 0);
+    if (__ballot(e != 0) == 0) {  // none of the wave's rows in this pass takes an other value (sparse inner selections)
 #pragma unroll
-      for (uint32_t j = 0; j < V; ++j) o.v[j] = fill;
+      for (uint32_t j = 0; j < V; ++j) vec_set<ES>(o, j, pick<T>(sel, j, fill2, fill));
     } else {
-      uint32_t x = base + s_pref[q0 >> 6] + (uint32_t)__popcll(wd & ((1ull << b) - 1ull));  // inner row of the first selected row
-      x = x < last1 ? x : last1;
-      const uint32_t xr = x - w0 * 64;                           // relative to the first staged inner word
-      const uint32_t d = xr >> 5;
-      uint32_t ib = __builtin_amdgcn_alignbit(ib32[d + 1], ib32[d], xr & 31u);  // inner bits of rows x, x + 1, ...
-      ib &= (1u << (uint32_t)__popc(sel)) - 1u;
-      o.q = make_u32x4(0, 0, 0, 0);
-      if (ib == 0) {
+      const uint32_t r2 = (uint32_t)ipref[d] + (uint32_t)__popc(lo & ((1u << sh) - 1u));  // inner rank at row x, relative to ob
+      const uint32_t klast = cnt2 - 1;  // some e != 0 here, so cnt2 != 0
 #pragma unroll
-        for (uint32_t j = 0; j < V; ++j) vec_set<ES>(o, j, ((sel >> j) & 1u) ? fill2 : fill);
-      } else {
-        const uint64_t wd2 = s_bits[W + (xr >> 6)];
-        uint32_t r2 = s_pref[W + (xr >> 6)] + (uint32_t)__popcll(wd2 & ((1ull << (xr & 63)) - 1ull));  // inner rank at row x
-#pragma unroll
-        for (uint32_t j = 0; j < V; ++j) {
-          T v = fill;
-          if ((sel >> j) & 1u) {
-            v = fill2;
-            if (ib & 1u) {
-              // inner ranks come from the same bitmap words as [ob, oe), so r2 lies inside;
-              // one unsigned clamp keeps a damaged input inside the stage all the same
-              const uint32_t k = r2 - ob;
-              v = cnt2 ? vals.at(k < cnt2 ? k : cnt2 - 1) : (T)0;
-              ++r2;
-            }
-            ib >>= 1;
-          }
-          vec_set<ES>(o, j, v);
-        }
+      for (uint32_t j = 0; j < V; ++j) {
+        const uint32_t k = r2 + (uint32_t)__popc(e & ((1u << j) - 1u));
+        const T v = vals.at(k < klast ? k : klast);
+        vec_set<ES>(o, j, pick<T>(e, j, v, pick<T>(sel, j, fill2, fill)));
       }
     }
-    store_vec<ES>(dst, q0, tile_rows, o);
+    store_vec_padded<ES>(dst, q0, tile_rows, o);
   }
-  (void)rows1;
+#ifdef NBL_PHASE_TIMING
+  __builtin_amdgcn_sched_barrier(0);
+  if (threadIdx.x == 0) {  // the loop's instructions, stores issued but not waited for
+    unsigned long long* tp_ = reinterpret_cast<unsigned long long*>(smem + kSmemBytes);
+    const unsigned long long t_ = __builtin_readcyclecounter();
+    g_phase[(blockIdx.x & (kPhaseTiles - 1)) * 8 + 6] = (uint32_t)(t_ - *tp_);
+    *tp_ = t_;
+  }
+#endif
 }
 
 // NullableEncoding::materialize (encodings/NullableEncoding.h:207-236): row i
@@ -1548,9 +1640,10 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
   static_assert(TE * ES == kTileBytes && W <= kBlock, "tile geometry");
   const uint32_t base = sload32(a.parts + pslot);
   const uint32_t next = sload32(a.parts + pslot + 1);  // the node's total sits behind its last partial
-  uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem + kStageBytes);         // W <= 256 words
-  uint32_t* s_pref = reinterpret_cast<uint32_t*>(smem + kStageBytes + 2048);  // W words
+  uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem + kStageBytes);         // W <= 256 words, read back as 2 W dwords
+  uint16_t* s_pref = reinterpret_cast<uint16_t*>(smem + kStageBytes + 2048);  // 2 W prefixes, one per dword
   uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + kStageBytes + 3072);
+  const uint32_t* bits32 = reinterpret_cast<const uint32_t*>(s_bits);
   const uint64_t rows = nd.rows;
   const uint64_t p0 = (uint64_t)tile * TE;
   const uint32_t tile_rows = rows - p0 < TE ? (uint32_t)(rows - p0) : TE;
@@ -1572,6 +1665,7 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
   // from the scanned partials, so the values can be fetched without waiting for
   // the bitmap.  Counts that disagree with the values child (corrupt input) are
   // clamped, never followed.
+  NBL_PHASE(smem, kSmemBytes, 1);  // descriptor and the tile's partials
   const uint32_t count = next - base < TE ? next - base : TE;
   const uint32_t avail = base < nvals ? nvals - base : 0u;
   const uint32_t n = count < avail ? count : avail;
@@ -1617,7 +1711,7 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
       StageRegs<5> regs;
       const uint32_t bit0 = rd.stage_begin(base, n, regs);
       write_nulls();
-      tile_rank_scan<W>(word, s_bits, s_pref, tmp);
+      tile_rank_scan32<W>(word, s_bits, s_pref, tmp);
       const auto idxs = rd.stage_end(regs, bit0, smem);
       __syncthreads();
       constexpr uint32_t IB = ES == 8 ? 4 : 2;  // rounds whose gathers are in flight together (8 rows)
@@ -1626,19 +1720,15 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
         uint32_t ix[IB][V], sel[IB];
 #pragma unroll
         for (uint32_t u = 0; u < IB; ++u) {
-          const uint32_t q0 = ((ib + u) * kBlock + threadIdx.x) * V;
-          const uint32_t qc = q0 < tile_rows ? q0 : 0;  // lanes past the tile repeat row 0 and store nothing
-          const uint64_t wd = s_bits[qc >> 6];
-          const uint32_t b = qc & 63;
-          uint32_t r = s_pref[qc >> 6] + (uint32_t)__popcll(wd & ((1ull << b) - 1ull));
-          const uint32_t bits = (uint32_t)(wd >> b);
-          sel[u] = bits & ((1u << V) - 1u);
+          const uint32_t q0 = ((ib + u) * kBlock + threadIdx.x) * V;  // rows past the tile have no bits and store nothing
+          uint32_t r;
+          vector_ranks<V>(bits32, s_pref, q0, r, sel[u]);
 #pragma unroll
           for (uint32_t j = 0; j < V; ++j) {
-            uint32_t i = idxs.at(r < last ? r : last);
+            const uint32_t rj = r + (uint32_t)__popc(sel[u] & ((1u << j) - 1u));
+            uint32_t i = idxs.at(rj < last ? rj : last);
             if (i > amax) { bad = true; i = amax; }
             ix[u][j] = i;
-            r += (bits >> j) & 1u;
           }
         }
         T x[IB][V];
@@ -1649,12 +1739,11 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
 #pragma unroll
         for (uint32_t u = 0; u < IB; ++u) {
           const uint32_t q0 = ((ib + u) * kBlock + threadIdx.x) * V;
-          if (q0 >= tile_rows) continue;
           Vec16<ES> o;
           o.q = make_u32x4(0, 0, 0, 0);
 #pragma unroll
-          for (uint32_t j = 0; j < V; ++j) vec_set<ES>(o, j, ((sel[u] >> j) & 1u) ? x[u][j] : fill);
-          store_vec<ES>(dst, q0, tile_rows, o);
+          for (uint32_t j = 0; j < V; ++j) vec_set<ES>(o, j, pick<T>(sel[u], j, x[u][j], fill));
+          store_vec_padded<ES>(dst, q0, tile_rows, o);
         }
       }
     });
@@ -1668,31 +1757,32 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
     StageRegs<5> regs;
     const uint32_t bit0 = rd.stage_begin(base, n, regs);
     write_nulls();
-    tile_rank_scan<W>(word, s_bits, s_pref, tmp);
+    tile_rank_scan32<W>(word, s_bits, s_pref, tmp);
     const auto vals = rd.stage_end(regs, bit0, smem);
     __syncthreads();
+    // no branch inside the wave: row j of a vector reads the value at rank
+    // r + (selected rows in front of j) whether it is selected or not, and the
+    // selection bit picks between it and the fill.  Rows past the tile have no
+    // bits and are not stored.
 #pragma unroll
     for (uint32_t it = 0; it < 4; ++it) {
       const uint32_t q0 = (it * kBlock + threadIdx.x) * V;
-      if (q0 >= tile_rows) break;
-      const uint64_t wd = s_bits[q0 >> 6];
-      const uint32_t b = q0 & 63;
-      uint32_t r = s_pref[q0 >> 6] + (uint32_t)__popcll(wd & ((1ull << b) - 1ull));
-      const uint32_t bits = (uint32_t)(wd >> b);  // bit j = row q0 + j (b + V <= 64)
+      uint32_t r, bits;
+      vector_ranks<V>(bits32, s_pref, q0, r, bits);
       Vec16<ES> o;
-      if ((bits & ((1u << V) - 1u)) == 0) {  // no selected row in this vector (sparse selections): all fill
+      o.q = make_u32x4(0, 0, 0, 0);
+      if (__ballot(bits != 0) == 0) {  // nothing selected in the wave's rows of this pass (sparse selections)
 #pragma unroll
-        for (uint32_t j = 0; j < V; ++j) o.v[j] = fill;
+        for (uint32_t j = 0; j < V; ++j) vec_set<ES>(o, j, fill);
       } else {
-        o.q = make_u32x4(0, 0, 0, 0);
 #pragma unroll
         for (uint32_t j = 0; j < V; ++j) {
-          const T v = vals.at(r < last ? r : last);
-          vec_set<ES>(o, j, ((bits >> j) & 1u) ? v : fill);
-          r += (bits >> j) & 1u;
+          const uint32_t rj = r + (uint32_t)__popc(bits & ((1u << j) - 1u));
+          const T v = vals.at(rj < last ? rj : last);
+          vec_set<ES>(o, j, pick<T>(bits, j, v, fill));
         }
       }
-      store_vec<ES>(dst, q0, tile_rows, o);
+      store_vec_padded<ES>(dst, q0, tile_rows, o);
     }
   });
 }
@@ -2275,13 +2365,16 @@ __device__ __forceinline__ NodeDesc load_node(const NodeDesc* p) {
 // One kernel per operation (used when the plan is not fused: profiling, tuning).
 template <uint32_t OP>
 __device__ __forceinline__ void single_op_kernel(const KArgs& a) {
-  __shared__ __align__(16) uint8_t smem[kSmemBytes];
+  __shared__ __align__(16) uint8_t smem[kSmemBytes + kPhaseBytes];
+  NBL_PHASE_BEGIN(smem, kSmemBytes);
   TileRef tr;
   tr.node = sload32(&a.tiles[blockIdx.x].node);
   tr.tile = sload32(&a.tiles[blockIdx.x].tile);
   const uint32_t aux = sload32(a.tile_aux + blockIdx.x);
+  NBL_PHASE(smem, kSmemBytes, 0);  // tile entry
   const NodeDesc nd = load_node(a.nodes + tr.node);
   run_op<OP>(a, nd, tr.tile & kTileMask, smem, aux);
+  NBL_PHASE(smem, kSmemBytes, 7);  // stores acknowledged
 }
 #define NBL_KERNEL_ES(name, KID) \
   template <int ES> __global__ __launch_bounds__(256, 8) void name(KArgs a) { single_op_kernel<make_op(KID, ES)>(a); }
@@ -2331,7 +2424,7 @@ __device__ __forceinline__ KArgs load_args(KArgsSegment k) {
 
 template <bool LAST>
 __global__ __launch_bounds__(256, 8) void k_level(KArgs) {
-  __shared__ __align__(16) uint8_t smem[kSmemBytes];
+  __shared__ __align__(16) uint8_t smem[kSmemBytes + kPhaseBytes];
   const KArgsSegment ka = (KArgsSegment)__builtin_amdgcn_kernarg_segment_ptr();
   TileRef tr;
   tr.node = sload32(&ka->tiles[blockIdx.x].node);
@@ -2379,6 +2472,13 @@ __global__ __launch_bounds__(256, 8) void k_level(KArgs) {
 // `kernel` is a KernelId, or K_LEVEL / K_LEVEL_LAST for a fused launch (then
 // `es` is ignored).  Kernels whose body does not depend on the element size
 // take any `es`.
+#ifdef NBL_PHASE_TIMING
+extern "C" int nbl_phase_read(uint32_t* out, uint32_t n_tiles) {
+  if (n_tiles > nbl::kPhaseTiles) n_tiles = nbl::kPhaseTiles;
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(nbl::g_phase), sizeof(uint32_t) * 8 * n_tiles) == hipSuccess ? 0 : -1;
+}
+#endif
+
 extern "C" int nbl_launch_kernel(uint32_t kernel, uint32_t es, const nbl::KArgs* args, void* stream) {
   using namespace nbl;
   const KArgs a = *args;

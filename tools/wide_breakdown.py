@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Last-level time of wide-table columns per (non-null fraction, values kind)
 group: 1250 columns of 100,000 rows each (tuning aid, needs a GPU).
-Usage: python tools/wide_breakdown.py [columns]"""
+Usage: python tools/wide_breakdown.py [columns] [nested|plain] [fraction]
+(the last two restrict the run to one group, e.g. under a counter pass)"""
 import os
 import sys
 
@@ -16,6 +17,8 @@ from nimble_amd import workloads  # noqa: E402
 from nimble_amd.decoder import BatchDecoder, Plan  # noqa: E402
 
 columns = int(sys.argv[1]) if len(sys.argv) > 1 else 1250
+only_kind = sys.argv[2] if len(sys.argv) > 2 else None
+only_frac = float(sys.argv[3]) if len(sys.argv) > 3 else None
 rows = 100_000
 
 
@@ -38,6 +41,8 @@ def column(c, frac, nested):
 
 for nested in (False, True):
     for frac in (0.01, 0.05, 0.2, 0.8):
+        if (only_kind and only_kind != ("nested" if nested else "plain")) or (only_frac is not None and only_frac != frac):
+            continue
         # a few distinct columns repeated: generation time, not decode time, is what this saves
         distinct = [column(c, frac, nested) for c in range(25)]
         chunks = [distinct[i % 25] for i in range(columns)]
