@@ -98,6 +98,10 @@ enum NodeFlags : uint32_t {
                              // partials (part_base, aux2 = rows per parent tile; NF_INVERT_SEL: count the zero bits)
   NF_SPARSE_DENSE = 1u << 9, // K_SPARSE_BITS: tiles of kBitTileRows rows instead of kSparseTileRows
   NF_BOOL_BYTES = 1u << 10,  // K_RLE_EXPAND_BOOL: the node is a chunk's root: self = its values in out, one byte per row
+  NF_WHOLE_NODE = 1u << 11,  // K_SPARSE_BITS / K_REDUCE_POPC: one workgroup holds the whole node (<= kWholeTileRows rows).
+                             // When it emits rank partials (NF_EMIT_PARTS, or always for K_REDUCE_POPC) it writes them
+                             // already scanned, with the node's totals (n_parts / total_idx are the parent's), so the
+                             // parent needs no scan step: one launch level less for columns of up to 131072 rows
   NF_FRAME_BITS = 1u << 4,   // K_FRAME_UNPACK: FOR (u64 bit offsets, no raw marker) instead of
                              // BlockBitPacking (u32 byte offsets, width 255 = raw block)
 };
@@ -167,6 +171,8 @@ constexpr uint32_t kPopcWordsPerThread = 4;  // K_REDUCE_POPC: bitmap words per 
 constexpr uint32_t kPopcTileRows = kBitTileRows * kPopcWordsPerThread;
 constexpr uint32_t kSparseTileWords = 1024;  // words per tile of the positions -> bitmap step (65536 rows)
 constexpr uint32_t kSparseTileRows = kSparseTileWords * 64;
+constexpr uint32_t kWholeTileWords = 2048;   // words of a bitmap that one workgroup builds or counts alone (NF_WHOLE_NODE)
+constexpr uint32_t kWholeTileRows = kWholeTileWords * 64;
 constexpr uint32_t kVarintTile = 4096;      // encoded bytes per varint tile
 // Rows per tile of the rank-scatter (Nullable / MainlyConstant) of `es`-byte elements.
 constexpr uint32_t select_tile_rows(uint32_t es) { return kTileBytes / es; }

@@ -823,6 +823,21 @@ __device__ __forceinline__ void body_reduce_sum(const KArgs& a, const NodeDesc& 
   if (threadIdx.x == 0) a.parts[nd.part_base + tile] = tot;
 }
 
+// Sum of `s` over the aligned group of `sub` consecutive threads (sub = 32, 64,
+// 128 or 256, workgroup uniform; tmp holds 4 words; every thread calls).
+__device__ __forceinline__ uint32_t group_sum(uint32_t s, uint32_t sub, uint32_t* tmp) {
+#pragma unroll
+  for (int d = 16; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);  // sum of the aligned 32-lane group
+  if (sub >= 64) s += __shfl_xor(s, 32, 64);                    // sum of the wave
+  if (sub > 64) {
+    __syncthreads();
+    if (lane_id() == 0) tmp[wave_id()] = s;
+    __syncthreads();
+    s = sub == 128 ? tmp[wave_id() & 2u] + tmp[(wave_id() & 2u) + 1] : tmp[0] + tmp[1] + tmp[2] + tmp[3];
+  }
+  return s;
+}
+
 // Rank partials of WPT * kBlock consecutive bitmap words, word
 // (tile * WPT + u) * kBlock + threadIdx.x counted in cnt[u]: one partial per
 // consumer tile of `sub` words (32, 64, 128 or 256) to parts[part_base + ..].
@@ -833,17 +848,41 @@ __device__ __forceinline__ void emit_rank_partials(const KArgs& a, uint32_t part
   for (uint32_t u = 0; u < WPT; ++u) {
     const uint64_t w = ((uint64_t)tile * WPT + u) * kBitTileWords + threadIdx.x;
     const bool live = w * 64 < rows;
-    uint32_t s = cnt[u];
-#pragma unroll
-    for (int d = 16; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);  // sum of the aligned 32-lane group
-    if (sub >= 64) s += __shfl_xor(s, 32, 64);                    // sum of the wave
-    if (sub > 64) {
-      __syncthreads();
-      if (lane_id() == 0) tmp[wave_id()] = s;
-      __syncthreads();
-      s = sub == 128 ? tmp[wave_id() & 2u] + tmp[(wave_id() & 2u) + 1] : tmp[0] + tmp[1] + tmp[2] + tmp[3];
-    }
+    const uint32_t s = group_sum(cnt[u], sub, tmp);
     if (live && (threadIdx.x & (sub - 1)) == 0) a.parts[part_base + (uint32_t)(w / sub)] = s;
+  }
+}
+
+// The same for a node that one workgroup holds alone (word u * kBlock +
+// threadIdx.x counted in cnt[u], zero past the node's rows): the partials are
+// written as the scan step would leave them -- exclusive prefixes, the total
+// behind the last one and in totals[total_idx], the node's flag word cleared --
+// so no scan step runs for the node.  n_parts <= 64 (a consumer tile has at
+// least 2048 rows, the node at most kWholeTileRows); lds: 4 + 64 words that
+// no thread still reads.
+template <uint32_t WPT>
+__device__ __forceinline__ void emit_scanned_partials(const KArgs& a, uint32_t part_base, uint32_t n_parts, uint32_t total_idx,
+                                                      uint32_t sub, const uint32_t (&cnt)[WPT], uint32_t* lds) {
+  static_assert(WPT * kBlock == kWholeTileWords, "one workgroup, the whole node");
+  uint32_t* s_part = lds + 4;
+  __syncthreads();  // the caller's threads may still be reading what lds held
+#pragma unroll
+  for (uint32_t u = 0; u < WPT; ++u) {
+    const uint32_t s = group_sum(cnt[u], sub, lds);
+    const uint32_t slot = (u * kBlock + threadIdx.x) / sub;
+    if ((threadIdx.x & (sub - 1)) == 0 && slot < 64) s_part[slot] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const uint32_t np = n_parts < 64 ? n_parts : 64;
+    const uint32_t v = threadIdx.x < np ? s_part[threadIdx.x] : 0u;
+    const uint32_t incl = wave_incl_scan(v);
+    if (threadIdx.x < np) a.parts[part_base + threadIdx.x] = incl - v;
+    if (threadIdx.x == 63) {
+      a.parts[part_base + np] = incl;
+      a.totals[total_idx] = incl;
+      a.totals[total_idx + 1] = 0;
+    }
   }
 }
 
@@ -851,14 +890,28 @@ __device__ __forceinline__ void emit_rank_partials(const KArgs& a, uint32_t part
 // kPopcTileRows rows (kPopcWordsPerThread 64-bit words per thread, all loaded
 // before the first is counted) and emits one partial per consumer tile of
 // nd.aux2 rows.
-__device__ __forceinline__ void body_reduce_popc(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
+template <uint32_t WPT>
+__device__ __forceinline__ void reduce_popc_words(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint32_t (&cnt)[WPT]) {
   const BitsReader sel(nd.sel, a, (nd.flags & NF_INVERT_SEL) != 0);
-  uint32_t cnt[kPopcWordsPerThread];
+  uint64_t wd[WPT];
 #pragma unroll
-  for (uint32_t u = 0; u < kPopcWordsPerThread; ++u) {
-    const uint64_t w = ((uint64_t)tile * kPopcWordsPerThread + u) * kBitTileWords + threadIdx.x;
-    cnt[u] = w * 64 < nd.sel.rows ? (uint32_t)__popcll(sel.word(w)) : 0u;
+  for (uint32_t u = 0; u < WPT; ++u) {  // every word requested before the first is counted
+    const uint64_t w = ((uint64_t)tile * WPT + u) * kBitTileWords + threadIdx.x;
+    wd[u] = w * 64 < nd.sel.rows ? sel.word(w) : 0ull;
   }
+#pragma unroll
+  for (uint32_t u = 0; u < WPT; ++u) cnt[u] = (uint32_t)__popcll(wd[u]);
+}
+__device__ __forceinline__ void body_reduce_popc(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
+  if (nd.flags & NF_WHOLE_NODE) {  // the planner's choice for nodes of up to kWholeTileRows rows: counted and scanned here
+    constexpr uint32_t WPT = kWholeTileWords / kBlock;
+    uint32_t cnt[WPT];
+    reduce_popc_words<WPT>(a, nd, 0, cnt);
+    emit_scanned_partials<WPT>(a, nd.part_base, nd.n_parts, nd.total_idx, (uint32_t)(nd.aux2 >> 6), cnt, reinterpret_cast<uint32_t*>(smem));
+    return;
+  }
+  uint32_t cnt[kPopcWordsPerThread];
+  reduce_popc_words<kPopcWordsPerThread>(a, nd, tile, cnt);
   emit_rank_partials<kPopcWordsPerThread>(a, nd.part_base, (uint32_t)(nd.aux2 >> 6), nd.sel.rows, tile, cnt, reinterpret_cast<uint32_t*>(smem));
 }
 
@@ -1226,29 +1279,41 @@ __device__ __forceinline__ void sparse_bits_tile(const KArgs& a, const NodeDesc&
   const uint64_t p1 = p0 + TR < rows ? p0 + TR : rows;
   uint64_t* dst = reinterpret_cast<uint64_t*>(a.work + nd.self.off);
   with_reader<4>(nd.c0, a, [&](auto rd) {
+    // the node's first tile starts at position 0 and its last one ends with the
+    // list: no search (a node of one tile does none at all)
     if (wave_id() == 0) {
       const uint32_t key = (uint32_t)p0;
-      uint32_t k = wave_first_true(K, [&](uint32_t i) { return rd.get(i) >= key; });
+      uint32_t k = 0;
+      if (tile != 0) k = wave_first_true(K, [&](uint32_t i) { return rd.get(i) >= key; });
       if (lane_id() == 0) s_k[0] = k;
     } else if (wave_id() == 1) {
       const uint32_t key = (uint32_t)p1;
-      uint32_t k = wave_first_true(K, [&](uint32_t i) { return rd.get(i) >= key; });
+      uint32_t k = K;
+      if (p1 < rows) k = wave_first_true(K, [&](uint32_t i) { return rd.get(i) >= key; });
       if (lane_id() == 0) s_k[1] = k;
     }
 #pragma unroll
     for (uint32_t u = 0; u < WPT; ++u) s_bits[u * kBlock + threadIdx.x] = 0;
     __syncthreads();
+    NBL_PHASE(smem, kSmemBytes, 1);  // descriptor, searches, zeroed tile
     const uint32_t lo = s_k[0], hi = s_k[1];
     uint32_t* bits32 = reinterpret_cast<uint32_t*>(s_bits);
-    // eight positions per thread in flight per round: every round waits for its loads
+    // Eight positions per thread and round, and the next round's loads are
+    // issued before this round's positions are used: a column of R rounds
+    // waits for about one memory round trip instead of R.
     constexpr uint32_t PPT = 8;
-    for (uint32_t j0 = lo + threadIdx.x; j0 < hi; j0 += PPT * kBlock) {
-      uint32_t pos[PPT];
+    uint32_t pos[PPT], nxt[PPT];
+    auto fetch = [&](uint32_t (&dst)[PPT], uint32_t j0) {
 #pragma unroll
       for (uint32_t u = 0; u < PPT; ++u) {
         const uint32_t j = j0 + u * kBlock;
-        pos[u] = rd.get(j < hi ? j : hi - 1);
+        dst[u] = rd.get(j < hi ? j : hi - 1);
       }
+    };
+    if (lo < hi) fetch(pos, lo + threadIdx.x);
+    for (uint32_t r0 = lo; r0 < hi; r0 += PPT * kBlock) {  // r0: workgroup uniform
+      const uint32_t j0 = r0 + threadIdx.x;
+      if (r0 + PPT * kBlock < hi) fetch(nxt, j0 + PPT * kBlock);
 #pragma unroll
       for (uint32_t u = 0; u < PPT; ++u) {
         const uint32_t j = j0 + u * kBlock;
@@ -1257,9 +1322,13 @@ __device__ __forceinline__ void sparse_bits_tile(const KArgs& a, const NodeDesc&
           atomicOr(&bits32[q >> 5], 1u << (q & 31));
         }
       }
+#pragma unroll
+      for (uint32_t u = 0; u < PPT; ++u) pos[u] = nxt[u];
     }
   });
+  NBL_PHASE(smem, kSmemBytes, 2);  // positions loaded and set
   __syncthreads();
+  NBL_PHASE(smem, kSmemBytes, 3);  // barrier
   // The parent that selects by this bitmap takes its rank partials from here
   // (NF_EMIT_PARTS: part_base / aux2 are the parent's, NF_INVERT_SEL = it
   // selects the zero bits), so no counting pass reads the bitmap back.
@@ -1278,7 +1347,11 @@ __device__ __forceinline__ void sparse_bits_tile(const KArgs& a, const NodeDesc&
       cnt[u] = (uint32_t)__popcll(zeros ? ~v & m : v);
     }
   }
-  if (emit) emit_rank_partials<WPT>(a, nd.part_base, (uint32_t)(nd.aux2 >> 6), rows, tile, cnt, reinterpret_cast<uint32_t*>(smem));
+  if constexpr (W == kWholeTileWords) {
+    if (emit) emit_scanned_partials<WPT>(a, nd.part_base, nd.n_parts, nd.total_idx, (uint32_t)(nd.aux2 >> 6), cnt, reinterpret_cast<uint32_t*>(smem));
+  } else {
+    if (emit) emit_rank_partials<WPT>(a, nd.part_base, (uint32_t)(nd.aux2 >> 6), rows, tile, cnt, reinterpret_cast<uint32_t*>(smem));
+  }
 }
 
 __device__ __forceinline__ void body_sparse_bits(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
@@ -1288,7 +1361,10 @@ __device__ __forceinline__ void body_sparse_bits(const KArgs& a, const NodeDesc&
   // the column is dense (NF_SPARSE_DENSE, the planner's choice): then a tile's
   // positions take several rounds of loads, and 16384-row tiles put four times
   // the workgroups on them.
-  if (nd.flags & NF_SPARSE_DENSE) sparse_bits_tile<kBitTileWords>(a, nd, tile, smem);
+  // A node of up to 131072 rows and few positions is one tile (NF_WHOLE_NODE):
+  // no search, and the rank partials it emits are final.
+  if (nd.flags & NF_WHOLE_NODE) sparse_bits_tile<kWholeTileWords>(a, nd, tile, smem);
+  else if (nd.flags & NF_SPARSE_DENSE) sparse_bits_tile<kBitTileWords>(a, nd, tile, smem);
   else sparse_bits_tile<kSparseTileWords>(a, nd, tile, smem);
 }
 

@@ -109,6 +109,10 @@ struct PNode {
 };
 
 constexpr size_t kDenseSparseMaxChunks = 512;
+// Positions a SparseBool column of up to kWholeTileRows rows may list and still be
+// built by one workgroup: two rounds of loads in a small batch, sixteen where
+// thousands of other tiles cover the wait.
+constexpr uint32_t kWholeMaxPositions = 4096, kWholeMaxPositionsBatch = 32768;
 
 struct Step {
   int level;
@@ -713,9 +717,16 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       // columns is bound by the fixed cost per tile instead (measured: +16%
       // on the bitmap level of a 5,000-column stripe with the small tiles).
       const bool dense = (uint64_t)C(0).rows * 32 > rows && layouts.size() <= kDenseSparseMaxChunks;
-      if (dense) d.flags |= NF_SPARSE_DENSE;
+      // A column of up to 131072 rows is one tile when its positions take few
+      // rounds of loads (16 rounds of 2048 in a batch that fills the chip anyway,
+      // 2 otherwise): no search for the tile's range of positions, and a parent
+      // selecting by the bitmap gets its rank partials already scanned.
+      const bool whole = rows > 0 && rows <= kWholeTileRows &&
+                         C(0).rows <= (layouts.size() > kDenseSparseMaxChunks ? kWholeMaxPositionsBatch : kWholeMaxPositions);
+      if (whole) d.flags |= NF_WHOLE_NODE;
+      else if (dense) d.flags |= NF_SPARSE_DENSE;
       const uint32_t dn = add_dnode(d);
-      add_step(lvl, K_SPARSE_BITS, 0, dn, div_up32(rows, dense ? kBitTileRows : kSparseTileRows));
+      add_step(lvl, K_SPARSE_BITS, 0, dn, whole ? 1u : div_up32(rows, dense ? kBitTileRows : kSparseTileRows));
       if (rows > 0) nn.sparse_dn = (int)dn;
       nn.ref = d.self; nn.ready = lvl + 1;
       break;
@@ -803,20 +814,31 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       // A SparseBool selection counts them while it builds the bitmap.
       const PNode& selc = nullable ? C(1) : C(0);
       const bool counted = selc.enc == ET_SPARSEBOOL && selc.sparse_dn >= 0 && selc.rows == rows;
+      // a node that one workgroup counts alone leaves its partials scanned: no scan step
+      bool scanned = false;
       if (counted) {
         NodeDesc& sd = dnodes[(size_t)selc.sparse_dn];
         sd.flags |= NF_EMIT_PARTS | (nullable ? 0u : (uint32_t)NF_INVERT_SEL);
         sd.part_base = d.part_base;
         sd.aux2 = trows;
+        if (sd.flags & NF_WHOLE_NODE) {
+          sd.n_parts = d.n_parts;
+          sd.total_idx = d.total_idx;
+          scanned = true;
+        }
+      } else if (rows > 0 && rows <= kWholeTileRows) {
+        d.flags |= NF_WHOLE_NODE;
+        scanned = true;
       }
       const int sel_lvl = selc.ready;
       const int scan_lvl = counted ? sel_lvl : sel_lvl + 1;
-      const int fin = std::max(lvl, scan_lvl + 1);
+      const int fin = std::max(lvl, scanned ? scan_lvl : scan_lvl + 1);
+      const uint32_t popc_tiles = scanned ? 1u : div_up32(rows, kPopcTileRows);
       if (nn.fused_select) {
         // the parent scatters for this node: it only counts and scans its ranks
         const uint32_t dn = add_dnode(d);
-        if (!counted) add_step(sel_lvl, K_REDUCE_POPC, 0, dn, div_up32(rows, kPopcTileRows));
-        add_step(scan_lvl, K_SCAN_TILES, 0, dn, 1, true);
+        if (!counted) add_step(sel_lvl, K_REDUCE_POPC, 0, dn, popc_tiles);
+        if (!scanned) add_step(scan_lvl, K_SCAN_TILES, 0, dn, 1, true);
         nn.sel_ref = d.sel;
         nn.sel_part_base = d.part_base;
         nn.sel_total_idx = d.total_idx;
@@ -827,8 +849,8 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       }
       d.self = nn.is_bool ? bits_ref() : mat_ref(es);
       const uint32_t dn = add_dnode(d);
-      if (!counted) add_step(sel_lvl, K_REDUCE_POPC, 0, dn, div_up32(rows, kPopcTileRows));  // each tile emits the partials of kPopcTileRows / trows consumer tiles
-      add_step(scan_lvl, K_SCAN_TILES, 0, dn, 1, true);
+      if (!counted) add_step(sel_lvl, K_REDUCE_POPC, 0, dn, popc_tiles);  // each tile emits the partials of kPopcTileRows / trows consumer tiles
+      if (!scanned) add_step(scan_lvl, K_SCAN_TILES, 0, dn, 1, true);
       if (nn.is_bool) add_step(fin, K_SELECT_BITS, 0, dn, nt);
       else add_step(fin, K_SELECT_SCATTER, es, dn, nt);
       nn.ref = d.self; nn.ready = fin + 1;

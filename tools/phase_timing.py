@@ -25,6 +25,8 @@ rows = 100_000
 def column(c):
     rng = np.random.default_rng(c)
     mask = rng.random(rows) < frac
+    if kind == "sparse":  # a root SparseBool column: marks 1-3 of the bitmap step survive the bit -> byte launch behind it
+        return (f"b{c}", E.encode(E.SparseBool(indices=E.FixedBitWidth()), mask, W.BOOL))
     nn = int(mask.sum())
     if kind != "nested":
         data = E.encode(E.Trivial(), rng.integers(0, 1 << 32, nn, dtype=np.uint64).astype(np.uint32), W.FLOAT)
@@ -53,13 +55,16 @@ dec.decode_profiled(0)
 ms = dec.profile_end()
 dec.status()
 ll = plan.launches()
-tiles = min(ll[-1][2], 1 << 18)
+which = int(os.environ.get("PHASE_LAUNCH", "-1"))  # launch whose records are read (the last one by default)
+tiles = min(ll[which][2], 1 << 18)
 rec = np.zeros((tiles, 8), dtype=np.uint32)
 assert lib.nbl_phase_read(rec.ctypes.data, tiles) == 0
 out = rec.astype(np.float64).sum(axis=0)
-names = ["tile entry", "descriptor + partials", "outer word + inner partials", "own staged values issued+arrived",
+names = ["tile entry", "descriptor + partials (sparse: desc, search, zeroed tile)", "outer word + inner partials", "own staged values issued+arrived",
          "scan + LDS writes", "barrier", "row loop (stores issued)", "stores acknowledged"]
-print(f"{kind} {frac}: last launch {ll[-1][0]} {ms[-1] * 1e3:.1f} us, {ll[-1][2]} tiles, {ms[-1] * 1e6 / ll[-1][2]:.2f} ns/tile")
+for i, (l, m) in enumerate(zip(ll, ms)):
+    print(f"  launch {i}: {l[0]:24s} {l[2]:7d} tiles {m * 1e3:8.1f} us")
+print(f"{kind} {frac}: launch {ll[which][0]} {ms[which] * 1e3:.1f} us, {ll[which][2]} tiles, {ms[which] * 1e6 / ll[which][2]:.2f} ns/tile")
 tot = 0
 for i, n in enumerate(names):
     c = out[i] / tiles
