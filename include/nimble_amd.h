@@ -55,6 +55,10 @@ typedef struct nbl_options {
   uint32_t struct_size;            /* sizeof(nbl_options) */
   uint32_t use_varint_row_count;   /* Encoding::Options::useVarintRowCount */
   uint32_t flags;                  /* NBL_PLAN_* (no counterpart in the reference) */
+  uint32_t wave_scatter_min_tiles; /* rank-scatter tiles of one cascade level from which the one-wave kernel
+                                    * gets a launch of its own (fewer run inside the level's fused launch);
+                                    * 0 = the library's default (32768).  Read when struct_size >= 16.
+                                    * No counterpart in the reference. */
 } nbl_options;
 
 /* By default every cascade level of the batch is ONE kernel launch whose tiles
@@ -64,6 +68,10 @@ typedef struct nbl_options {
 /* Also emit the alphabet (and the raw indices) of dictionary-encoded chunks,
  * so that a reader can hand out dictionary vectors without expanding them. */
 #define NBL_PLAN_KEEP_DICTIONARY 2u
+/* Keep every Nullable / MainlyConstant rank scatter on the four-wave tile
+ * kernel; by default columns whose tiles stage few values take the one-wave
+ * kernel (more tiles in flight per CU).  Same results; for tuning and tests. */
+#define NBL_PLAN_FOUR_WAVE_SCATTER 4u
 
 typedef struct nbl_plan nbl_plan;
 

@@ -57,6 +57,7 @@ enum KernelId : uint32_t {
   K_MATERIALIZE_FBW,   // root FixedBitWidth, window-per-vector fast path
   K_MATERIALIZE_RAW,   // root Trivial / byte-aligned FixedBitWidth: copy (+ baseline)
   K_FRAME_UNPACK,      // BlockBitPacking blocks / FOR frames: per-segment baseline + width
+  K_SELECT_SCATTER_WAVE,  // Nullable / MainlyConstant of 4- / 8-byte rows with few values per tile: one wave per tile
   K_COUNT,
   // Launch ids of the fused launches: one launch runs every step of a cascade
   // level, each tile naming its own operation (TileRef::tile, high byte).
@@ -74,12 +75,15 @@ constexpr uint32_t make_op(uint32_t kernel, uint32_t es) { return kernel * 4u + 
 // Kernel families whose code depends on the element size; the others always use slot 0.
 constexpr bool kernel_has_es(uint32_t k) {
   return k == K_MATERIALIZE || k == K_MATERIALIZE_FBW || k == K_MATERIALIZE_RAW || k == K_RLE_EXPAND ||
-         k == K_SELECT_SCATTER || k == K_DICT_GATHER || k == K_VARINT_DECODE || k == K_FRAME_UNPACK;
+         k == K_SELECT_SCATTER || k == K_DICT_GATHER || k == K_VARINT_DECODE || k == K_FRAME_UNPACK ||
+         k == K_SELECT_SCATTER_WAVE;
 }
 // Operations the fused level launch carries.  The block encodings are rare
 // (experimental in the reference) and their body would cost the fused kernel
 // registers it does not have to spare, so they keep a launch of their own.
-constexpr bool kernel_is_fusable(uint32_t k) { return k != K_FRAME_UNPACK; }
+// The one-wave rank scatter is a launch of its own by construction: 64-thread
+// workgroups with a quarter of the LDS, so that a CU holds 32 of its tiles.
+constexpr bool kernel_is_fusable(uint32_t k) { return k != K_FRAME_UNPACK && k != K_SELECT_SCATTER_WAVE; }
 constexpr uint32_t op_of(uint32_t kernel, uint32_t es) { return make_op(kernel, kernel_has_es(kernel) ? es : 1u); }
 
 enum NodeFlags : uint32_t {
@@ -176,5 +180,10 @@ constexpr uint32_t kWholeTileRows = kWholeTileWords * 64;
 constexpr uint32_t kVarintTile = 4096;      // encoded bytes per varint tile
 // Rows per tile of the rank-scatter (Nullable / MainlyConstant) of `es`-byte elements.
 constexpr uint32_t select_tile_rows(uint32_t es) { return kTileBytes / es; }
+// The one-wave rank scatter (K_SELECT_SCATTER_WAVE): 64 threads per tile and the
+// bytes of staged values a tile may need (a tile that needs more reads them
+// from memory row by row; the planner picks the kernel by the column's average).
+constexpr uint32_t kWaveBlock = 64;
+constexpr uint32_t kWaveStageBytes = 2432;
 
 }  // namespace nbl

@@ -339,32 +339,32 @@ struct StageRegs {
   u32x4 g[ROUNDS];
   uint32_t nvec;
 };
-template <int ROUNDS>
+template <int ROUNDS, uint32_t BS = kBlock>  // BS: threads of the workgroup
 __device__ __forceinline__ uint32_t stage_load(const uint8_t* p, uint32_t nbytes, StageRegs<ROUNDS>& regs) {
   const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(p) & 15u);
   const u32x4* asrc = reinterpret_cast<const u32x4*>(p - mis);
   const uint32_t nvec = (mis + nbytes + 4u + 15u) >> 4;
   regs.nvec = nvec;
-  if (nvec <= kBlock) {
+  if (nvec <= BS) {
     regs.g[0] = asrc[threadIdx.x < nvec ? threadIdx.x : nvec - 1];
     return mis;
   }
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
-    const uint32_t i = r * kBlock + threadIdx.x;
+    const uint32_t i = r * BS + threadIdx.x;
     regs.g[r] = asrc[i < nvec ? i : nvec - 1];
   }
   return mis;
 }
-template <int ROUNDS>
+template <int ROUNDS, uint32_t BS = kBlock>
 __device__ __forceinline__ void stage_store(const StageRegs<ROUNDS>& regs, u32x4* stage) {
-  if (regs.nvec <= kBlock) {
+  if (regs.nvec <= BS) {
     if (threadIdx.x < regs.nvec) stage[threadIdx.x] = regs.g[0];
     return;
   }
 #pragma unroll
   for (int r = 0; r < ROUNDS; ++r) {
-    const uint32_t i = r * kBlock + threadIdx.x;
+    const uint32_t i = r * BS + threadIdx.x;
     if (i < regs.nvec) stage[i] = regs.g[r];
   }
 }
@@ -514,22 +514,29 @@ struct Reader {
     }
   };
   __device__ __forceinline__ uint32_t bits_per_elem() const { return RK == RK_PTR ? 8u * CES : RK == RK_CONST ? 0u : w; }
-  __device__ __forceinline__ bool fits(uint32_t n) const { return (uint64_t)n * bits_per_elem() <= 8ull * kTileBytes; }
+  __device__ __forceinline__ bool fits(uint32_t n, uint32_t bytes = kTileBytes) const { return (uint64_t)n * bits_per_elem() <= 8ull * bytes; }
   // Staging in two halves: stage_begin issues the loads into registers,
-  // stage_end writes them to LDS (the caller synchronises after it)
-  __device__ __forceinline__ uint32_t stage_begin(uint64_t first, uint32_t n, StageRegs<5>& regs) const {
+  // stage_end writes them to LDS (the caller synchronises after it).
+  // ROUNDS * BS * 16 bytes must cover the range and its alignment slack.
+  template <int ROUNDS, uint32_t BS = kBlock>
+  __device__ __forceinline__ uint32_t stage_begin(uint64_t first, uint32_t n, StageRegs<ROUNDS>& regs) const {
     if constexpr (RK == RK_CONST) {
       regs.nvec = 0;
       return 0u;
     } else {
       const uint64_t bit = first * bits_per_elem();
       const uint32_t sh = (uint32_t)bit & 7u;
-      const uint32_t mis = stage_load<5>(p + (bit >> 3), (sh + n * bits_per_elem() + 7u) >> 3, regs);
+      const uint32_t mis = stage_load<ROUNDS, BS>(p + (bit >> 3), (sh + n * bits_per_elem() + 7u) >> 3, regs);
       return mis * 8u + sh;
     }
   }
-  __device__ __forceinline__ Staged stage_end(const StageRegs<5>& regs, uint32_t bit0, uint8_t* lds) const {
-    if constexpr (RK != RK_CONST) stage_store<5>(regs, reinterpret_cast<u32x4*>(lds));
+  template <int ROUNDS, uint32_t BS = kBlock>
+  __device__ __forceinline__ Staged stage_end(const StageRegs<ROUNDS>& regs, uint32_t bit0, uint8_t* lds) const {
+    if constexpr (RK != RK_CONST) stage_store<ROUNDS, BS>(regs, reinterpret_cast<u32x4*>(lds));
+    return Staged{*this, reinterpret_cast<const uint32_t*>(lds), bit0};
+  }
+  // the view of values that an earlier stage_end() left in LDS
+  __device__ __forceinline__ Staged staged_at(uint32_t bit0, const uint8_t* lds) const {
     return Staged{*this, reinterpret_cast<const uint32_t*>(lds), bit0};
   }
   __device__ __forceinline__ View view(uint64_t first) const {
@@ -1863,6 +1870,255 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
   });
 }
 
+// ------------------------------------------------------ K_SELECT_SCATTER_WAVE
+// The same rank scatter with ONE wave per 16 KiB tile, for columns whose tiles
+// stage few values (sparse selections; nested ones, whose staged values are
+// the few "other" ones).  A tile spends most of its life in a chain of
+// dependent loads -- tile entry, descriptor and partials, inner partials,
+// values -- each a trip to memory that the tile's own stores keep busy, and a
+// CU holds 8 four-wave workgroups but 32 one-wave ones: four times the chains
+// in flight for the same bytes, waves and instructions.  No barrier but the
+// wave's own; the four-wave body stays for dense selections, whose staged
+// values need its 16 KiB of LDS, and for the Dictionary / RLE values children.
+constexpr uint32_t kWaveBitsOff = kWaveStageBytes + 16;             // 64 outer words, up to 128 inner ones, a window's slack
+constexpr uint32_t kWaveBitsBytes = 192 * 8 + 16;
+constexpr uint32_t kWavePrefOff = kWaveBitsOff + kWaveBitsBytes;    // 384 16-bit prefixes (one per dword of bits)
+constexpr uint32_t kWaveDepOff = kWavePrefOff + 384 * 2;            // deposit table of the nested selection
+constexpr uint32_t kWaveSmemBytes = kWaveDepOff + 256;
+static_assert(kWaveSmemBytes * 32 <= 160 * 1024 && kWaveBitsOff % 16 == 0 && kWavePrefOff % 4 == 0, "32 one-wave workgroups per CU");
+
+template <int ES, typename RD>
+__device__ __forceinline__ void wave_select_nested(const KArgs& a, const NodeDesc& nd, const RD& rd, uint8_t* smem, uint64_t word,
+                                                   uint32_t base, uint32_t n, uint32_t tile_rows,
+                                                   typename ElemT<ES>::type* dst, typename ElemT<ES>::type fill) {
+  using T = typename ElemT<ES>::type;
+  constexpr uint32_t V = 16 / ES;
+  constexpr uint32_t TE = select_tile_rows(ES);
+  constexpr uint32_t W = TE / 64;
+  constexpr uint32_t ITS = TE / (kWaveBlock * V);
+  static_assert(W <= 64 && V <= 4, "one word per lane; deposit table of 4^V entries");
+  uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem + kWaveBitsOff);
+  uint16_t* s_pref = reinterpret_cast<uint16_t*>(smem + kWavePrefOff);
+  uint8_t* s_dep = smem + kWaveDepOff;
+  const uint32_t lane = threadIdx.x;
+  const T fill2 = (T)nd.aux3;
+  const uint32_t nothers = nd.c1.rows;
+  const uint32_t j0 = base / TE, j1 = (base + n - 1) / TE;    // inner tiles holding this tile's outer ranks (at most two)
+  uint32_t ob = sload32(a.parts + nd.part_base2 + j0);
+  uint32_t oe = sload32(a.parts + nd.part_base2 + j1 + 1);
+  ob = ob < nothers ? ob : nothers;                           // scan results of damaged input are clamped, never followed
+  oe = oe < nothers ? oe : nothers;
+  oe = oe < ob ? ob : oe;
+  const uint32_t cnt2 = oe - ob;
+  const bool staged = rd.fits(cnt2, kWaveStageBytes);
+  const uint32_t w0 = j0 * W;
+  const uint32_t nw = (base + n - 1) / 64 - w0 + 1;           // <= 2 W <= 128: two inner words per lane
+  const BitsReader inner(nd.c0, a, true);                     // MainlyConstant: other values where isCommon is 0
+  const uint64_t r0 = inner.word(w0 + (lane < nw ? lane : 0));
+  const uint64_t r1 = inner.word(w0 + (lane + 64 < nw ? lane + 64 : 0));
+  StageRegs<3> regs;
+  regs.nvec = 0;
+  uint32_t bit0 = 0;
+  if (staged && cnt2) bit0 = rd.template stage_begin<3, kWaveBlock>(ob, cnt2, regs);
+  for (uint32_t i = lane; i < (1u << (2 * V)); i += kWaveBlock) {  // deposit table, as in the four-wave body
+    const uint32_t sel = i & ((1u << V) - 1u);
+    uint32_t ib = i >> V, e = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < V; ++j) {
+      const uint32_t sj = (sel >> j) & 1u;
+      e |= (sj & ib) << j;
+      ib >>= sj;
+    }
+    s_dep[i] = (uint8_t)e;
+  }
+  tile_rank_scan32<W>(word, s_bits, s_pref, nullptr);
+  {
+    const uint64_t iw0 = lane < nw ? r0 : 0, iw1 = lane + 64 < nw ? r1 : 0;
+    const uint32_t a0 = (uint32_t)__popc((uint32_t)iw0), a1 = (uint32_t)__popc((uint32_t)(iw0 >> 32));
+    const uint32_t b0 = (uint32_t)__popc((uint32_t)iw1), b1 = (uint32_t)__popc((uint32_t)(iw1 >> 32));
+    const uint32_t i0 = wave_incl_scan(a0 + a1);
+    const uint32_t t0 = (uint32_t)__builtin_amdgcn_readlane((int)i0, 63);
+    const uint32_t i1 = wave_incl_scan(b0 + b1);
+    uint32_t* pref2 = reinterpret_cast<uint32_t*>(s_pref + 2 * W);
+    const uint32_t e0 = i0 - a0 - a1, e1 = t0 + i1 - b0 - b1;
+    s_bits[W + lane] = iw0; pref2[lane] = e0 | ((e0 + a0) << 16);
+    s_bits[W + 64 + lane] = iw1; pref2[64 + lane] = e1 | ((e1 + b0) << 16);
+  }
+  rd.template stage_end<3, kWaveBlock>(regs, bit0, smem);
+  __syncthreads();
+  const uint32_t* ob32 = reinterpret_cast<const uint32_t*>(s_bits);
+  const uint32_t* ib32 = reinterpret_cast<const uint32_t*>(s_bits + W);
+  const uint16_t* ipref = s_pref + 2 * W;
+  const uint32_t xoff = base - w0 * 64;
+  const uint32_t xlast = xoff + n - 1;
+  const uint32_t last2 = nothers ? nothers - 1 : 0;
+  // [ob, oe) are the other values of the whole inner tiles this tile touches;
+  // where those are more than the stage holds, the inner ranks of the tile's
+  // first and last row (known now) bound what it reads itself: at most n.
+  uint32_t kfirst = 0, kcount = cnt2;
+  bool have = staged;
+  if (!staged) {
+    auto rank_at = [&](uint32_t x) { return (uint32_t)ipref[x >> 5] + (uint32_t)__popc(ib32[x >> 5] & ((1u << (x & 31)) - 1u)); };
+    kfirst = rank_at(xoff);
+    const uint32_t kend = rank_at(xlast) + ((ib32[xlast >> 5] >> (xlast & 31)) & 1u);
+    kfirst = kfirst < cnt2 ? kfirst : cnt2;
+    kcount = kend > kfirst ? kend - kfirst : 0u;
+    kcount = kcount < cnt2 - kfirst ? kcount : cnt2 - kfirst;
+    have = rd.fits(kcount, kWaveStageBytes);
+    if (have) {
+      regs.nvec = 0;
+      bit0 = 0;
+      if (kcount) bit0 = rd.template stage_begin<3, kWaveBlock>((uint64_t)ob + kfirst, kcount, regs);
+      rd.template stage_end<3, kWaveBlock>(regs, bit0, smem);
+      __syncthreads();
+    }
+  }
+  const auto vals = rd.staged_at(bit0, smem);
+  if (!have) {  // a tile that reads more other values than the stage holds: row by row from global memory
+#pragma unroll 1
+    for (uint32_t q = lane; q < tile_rows; q += kWaveBlock) {
+      const uint32_t wd = ob32[q >> 5];
+      T v = fill;
+      if ((wd >> (q & 31)) & 1u) {
+        uint32_t x = xoff + s_pref[q >> 5] + (uint32_t)__popc(wd & ((1u << (q & 31)) - 1u));
+        x = x < xlast ? x : xlast;
+        const uint32_t wd2 = ib32[x >> 5];
+        v = fill2;
+        if (((wd2 >> (x & 31)) & 1u) && nothers) {
+          const uint32_t r2 = ob + ipref[x >> 5] + (uint32_t)__popc(wd2 & ((1u << (x & 31)) - 1u));
+          v = rd.get(r2 < last2 ? r2 : last2);
+        }
+      }
+      dst[q] = v;
+    }
+    return;
+  }
+#pragma unroll 4
+  for (uint32_t it = 0; it < ITS; ++it) {
+    const uint32_t q0 = (it * kWaveBlock + lane) * V;
+    uint32_t r, sel;
+    vector_ranks<V>(ob32, s_pref, q0, r, sel);
+    uint32_t x = xoff + r;
+    x = x < xlast ? x : xlast;
+    const uint32_t d = x >> 5, sh = x & 31u;
+    const uint32_t lo = ib32[d], hi = ib32[d + 1];
+    const uint32_t ib = __builtin_amdgcn_alignbit(hi, lo, sh) & ((1u << V) - 1u);
+    uint32_t e = s_dep[(ib << V) | sel];
+    e = kcount ? e : 0u;
+    Vec16<ES> o;
+    o.q = make_u32x4(0, 0, 0, 0);
+    if (__ballot(e != 0) == 0) {
+#pragma unroll
+      for (uint32_t j = 0; j < V; ++j) vec_set<ES>(o, j, pick<T>(sel, j, fill2, fill));
+    } else {
+      // inner rank at row x, relative to the first staged value (an unsigned
+      // wrap on damaged input ends in the clamp)
+      const uint32_t r2 = (uint32_t)ipref[d] + (uint32_t)__popc(lo & ((1u << sh) - 1u)) - kfirst;
+      const uint32_t klast = kcount - 1;
+#pragma unroll
+      for (uint32_t j = 0; j < V; ++j) {
+        const uint32_t k = r2 + (uint32_t)__popc(e & ((1u << j) - 1u));
+        const T v = vals.at(k < klast ? k : klast);
+        vec_set<ES>(o, j, pick<T>(e, j, v, pick<T>(sel, j, fill2, fill)));
+      }
+    }
+    store_vec_padded<ES>(dst, q0, tile_rows, o);
+  }
+}
+
+template <int ES>
+__device__ __forceinline__ void body_select_scatter_wave(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem, uint32_t pslot) {
+  using T = typename ElemT<ES>::type;
+  constexpr uint32_t V = 16 / ES;
+  constexpr uint32_t TE = select_tile_rows(ES);
+  constexpr uint32_t W = TE / 64;
+  constexpr uint32_t ITS = TE / (kWaveBlock * V);
+  static_assert(ES >= 4 && W <= 64, "4- and 8-byte rows: at most one bitmap word per lane");
+  const uint32_t lane = threadIdx.x;
+  const uint32_t base = sload32(a.parts + pslot);
+  const uint32_t next = sload32(a.parts + pslot + 1);
+  uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem + kWaveBitsOff);
+  uint16_t* s_pref = reinterpret_cast<uint16_t*>(smem + kWavePrefOff);
+  const uint32_t* bits32 = reinterpret_cast<const uint32_t*>(s_bits);
+  const uint64_t rows = nd.rows;
+  const uint64_t p0 = (uint64_t)tile * TE;
+  const uint32_t tile_rows = rows - p0 < TE ? (uint32_t)(rows - p0) : TE;
+  const bool invert = (nd.flags & NF_INVERT_SEL) != 0;
+  const bool nested = (nd.flags & NF_NESTED_SELECT) != 0;
+  T* dst = reinterpret_cast<T*>(self_ptr(nd, a)) + p0;
+  const uint32_t nvals = nested ? nd.c0.rows : nd.c1.rows;
+  if (tile == 0 && lane == 0) {
+    bool bad = sload32(a.totals + nd.total_idx) != nvals;
+    if (nested) bad |= sload32(a.totals + nd.total_idx2) != nd.c1.rows;
+    if (bad) atomicOr(a.status, ST_SELECT_COUNT);
+  }
+  const uint32_t count = next - base < TE ? next - base : TE;
+  const uint32_t avail = base < nvals ? nvals - base : 0u;
+  const uint32_t n = count < avail ? count : avail;
+  const uint64_t w = (uint64_t)tile * W + lane;
+  uint64_t word = 0;
+  if (lane < W && w * 64 < rows) word = BitsReader(nd.sel, a, invert).word(w);
+  const T fill = (T)nd.aux;
+  if ((nd.flags & NF_WRITE_NULLS) && lane < W && w * 64 < rows)
+    reinterpret_cast<uint64_t*>(a.out + nd.aux_off)[w] = invert ? ~word & (w * 64 + 64 > rows ? wmask((uint32_t)(rows - w * 64)) : ~0ull) : word;
+  if (n == 0) {  // nothing selected (or nothing to select from): a fill
+    Vec16<ES> x;
+#pragma unroll
+    for (uint32_t j = 0; j < V; ++j) x.v[j] = fill;
+#pragma unroll 4
+    for (uint32_t it = 0; it < ITS; ++it) store_vec_padded<ES>(dst, (it * kWaveBlock + lane) * V, tile_rows, x);
+    return;
+  }
+  if (nested) {
+    with_reader<ES>(nd.c1, a, [&](auto rd) { wave_select_nested<ES>(a, nd, rd, smem, word, base, n, tile_rows, dst, fill); });
+    return;
+  }
+  with_reader<ES>(nd.c1, a, [&](auto rd) {
+    const bool staged = rd.fits(n, kWaveStageBytes);
+    StageRegs<3> regs;
+    regs.nvec = 0;
+    uint32_t bit0 = 0;
+    if (staged) bit0 = rd.template stage_begin<3, kWaveBlock>(base, n, regs);
+    tile_rank_scan32<W>(word, s_bits, s_pref, nullptr);
+    const auto vals = rd.template stage_end<3, kWaveBlock>(regs, bit0, smem);
+    __syncthreads();
+    const uint32_t last = n - 1;
+    if (!staged) {  // a tile denser than the column's average: its values row by row from global memory
+#pragma unroll 1
+      for (uint32_t q = lane; q < tile_rows; q += kWaveBlock) {
+        const uint32_t wd = bits32[q >> 5];
+        T v = fill;
+        if ((wd >> (q & 31)) & 1u) {
+          const uint32_t r = s_pref[q >> 5] + (uint32_t)__popc(wd & ((1u << (q & 31)) - 1u));
+          v = rd.get((uint64_t)base + (r < last ? r : last));
+        }
+        dst[q] = v;
+      }
+      return;
+    }
+#pragma unroll 4
+    for (uint32_t it = 0; it < ITS; ++it) {
+      const uint32_t q0 = (it * kWaveBlock + lane) * V;
+      uint32_t r, bits;
+      vector_ranks<V>(bits32, s_pref, q0, r, bits);
+      Vec16<ES> o;
+      o.q = make_u32x4(0, 0, 0, 0);
+      if (__ballot(bits != 0) == 0) {
+#pragma unroll
+        for (uint32_t j = 0; j < V; ++j) vec_set<ES>(o, j, fill);
+      } else {
+#pragma unroll
+        for (uint32_t j = 0; j < V; ++j) {
+          const uint32_t rj = r + (uint32_t)__popc(bits & ((1u << j) - 1u));
+          const T v = vals.at(rj < last ? rj : last);
+          vec_set<ES>(o, j, pick<T>(bits, j, v, fill));
+        }
+      }
+      store_vec_padded<ES>(dst, q0, tile_rows, o);
+    }
+  });
+}
+
 // Nullable<bool>: scatter a bitmap of values by the selection bitmap.
 // Tile = 16384 rows; each wave resolves one output word per pass (lane = bit).
 __device__ __forceinline__ void body_select_bits(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
@@ -2477,6 +2733,15 @@ NBL_KERNEL(k_copy_bytes, K_COPY_BYTES)
 NBL_KERNEL_ES(k_frame_unpack, K_FRAME_UNPACK)
 #undef NBL_KERNEL_ES
 #undef NBL_KERNEL
+template <int ES>
+__global__ __launch_bounds__(kWaveBlock, 8) void k_select_scatter_wave(KArgs a) {
+  __shared__ __align__(16) uint8_t smem[kWaveSmemBytes];
+  const uint32_t node = sload32(&a.tiles[blockIdx.x].node);
+  const uint32_t tile = sload32(&a.tiles[blockIdx.x].tile) & kTileMask;
+  const uint32_t aux = sload32(a.tile_aux + blockIdx.x);
+  const NodeDesc nd = load_node(a.nodes + node);
+  body_select_scatter_wave<ES>(a, nd, tile, smem, aux);
+}
 
 // The fused launch: one grid runs every step of one cascade level of the whole
 // batch; each workgroup reads its operation from its tile entry (workgroup
@@ -2595,6 +2860,11 @@ extern "C" int nbl_launch_kernel(uint32_t kernel, uint32_t es, const nbl::KArgs*
     case K_STRING_VIEWS: hipLaunchKernelGGL(k_string_views, grid, block, 0, s, a); break;
     case K_COPY_BYTES: hipLaunchKernelGGL(k_copy_bytes, grid, block, 0, s, a); break;
     case K_FRAME_UNPACK: NBL_BY_ES(k_frame_unpack); break;
+    case K_SELECT_SCATTER_WAVE:
+      if (es == 4) hipLaunchKernelGGL(k_select_scatter_wave<4>, grid, dim3(kWaveBlock), 0, s, a);
+      else if (es == 8) hipLaunchKernelGGL(k_select_scatter_wave<8>, grid, dim3(kWaveBlock), 0, s, a);
+      else return -1;
+      break;
     default: return -1;
   }
 #undef NBL_BY_ES

@@ -113,6 +113,8 @@ constexpr size_t kDenseSparseMaxChunks = 512;
 // built by one workgroup: two rounds of loads in a small batch, sixteen where
 // thousands of other tiles cover the wait.
 constexpr uint32_t kWholeMaxPositions = 4096, kWholeMaxPositionsBatch = 32768;
+// Tiles of one level and element size from which the one-wave rank scatter gets its own launch.
+constexpr uint64_t kWaveLaunchMinTiles = 32768;
 
 struct Step {
   int level;
@@ -140,7 +142,7 @@ const char* kKernelNames[K_COUNT] = {
     "k_materialize", "k_bits_to_bytes", "k_reduce_sum", "k_reduce_popc", "k_reduce_varint",
     "k_scan_tiles", "k_rle_ends", "k_rle_expand", "k_rle_expand_bool", "k_sparse_bits",
     "k_select_scatter", "k_dict_gather", "k_varint_decode", "k_string_views", "k_copy_bytes",
-    "k_select_bits", "k_materialize_fbw", "k_materialize_raw", "k_frame_unpack"};
+    "k_select_bits", "k_materialize_fbw", "k_materialize_raw", "k_frame_unpack", "k_select_scatter_wave"};
 
 }  // namespace
 
@@ -162,6 +164,8 @@ struct nbl_plan {
   std::vector<uint32_t> tile_aux;         // parallel to tiles (KArgs::tile_aux)
   bool keep_dictionary = false;  // also emit alphabet + indices of dictionary chunks
   bool fused = true;          // one launch per cascade level (default) or one per (level, kernel, element size)
+  bool wave_scatter = true;   // sparse rank scatters on the one-wave kernel (default) or every one on the four-wave tile
+  uint64_t wave_min_tiles = kWaveLaunchMinTiles;  // tiles of one level and element size that make a one-wave launch
   int cur_chunk = -1;         // chunk being planned
   std::vector<uint8_t> blob;  // NodeDesc[] | TileRef[] image uploaded to work
   uint64_t tiles_off = 0, aux_off = 0;
@@ -851,8 +855,17 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       const uint32_t dn = add_dnode(d);
       if (!counted) add_step(sel_lvl, K_REDUCE_POPC, 0, dn, popc_tiles);  // each tile emits the partials of kPopcTileRows / trows consumer tiles
       if (!scanned) add_step(scan_lvl, K_SCAN_TILES, 0, dn, 1, true);
+      // Tiles that stage few values (a sparse selection, or a nested one whose
+      // staged values are the few "other" ones) go to the one-wave kernel: on the
+      // column's average a tile may fill two thirds of that kernel's stage.
+      bool one_wave = wave_scatter && (es == 4 || es == 8) && !(d.flags & (NF_DICT_VALUES | NF_RLE_VALUES));
+      if (one_wave) {
+        const ColRef& v = d.c1;
+        const uint64_t bits = v.kind == COL_CONST ? 0u : (v.kind == COL_FBW ? v.width : 8u * es);
+        one_wave = (uint64_t)v.rows * bits / 8 * trows * 3 <= (uint64_t)kWaveStageBytes * 2 * rows;
+      }
       if (nn.is_bool) add_step(fin, K_SELECT_BITS, 0, dn, nt);
-      else add_step(fin, K_SELECT_SCATTER, es, dn, nt);
+      else add_step(fin, one_wave ? K_SELECT_SCATTER_WAVE : K_SELECT_SCATTER, es, dn, nt);
       nn.ref = d.self; nn.ready = fin + 1;
       break;
     }
@@ -1053,6 +1066,18 @@ void nbl_plan::finish() {
     if (st.owner >= 0) st.level += last_level - chunk_last[(size_t)st.owner];
   for (Step& st : steps)
     if (st.chunk >= 0) st.alg = chunk_alg[(size_t)st.chunk];
+  {
+    // The one-wave rank scatter is a launch of its own: worth it only where a
+    // level has enough of its tiles to fill the chip several times over (a
+    // 5,000-column stripe has ~10^5); fewer run as four-wave tiles inside the
+    // level's fused launch, where other work covers their waits.
+    std::vector<uint64_t> wave_tiles((size_t)(last_level + 1) * 4, 0);
+    for (const Step& st : steps)
+      if (st.kernel == K_SELECT_SCATTER_WAVE) wave_tiles[(size_t)st.level * 4 + es_slot(st.es)] += st.n_tiles;
+    for (Step& st : steps)
+      if (st.kernel == K_SELECT_SCATTER_WAVE && wave_tiles[(size_t)st.level * 4 + es_slot(st.es)] < wave_min_tiles)
+        st.kernel = K_SELECT_SCATTER;
+  }
   if (fused && last_level > 0) spread_free_steps(last_level);
   {  // stable counting sort by (level, filler, kernel, element size): wide tables have ~10 steps per column
     // within a level: the level's own fusable steps, the fillers, then the steps that launch on their own
@@ -1085,7 +1110,7 @@ void nbl_plan::finish() {
       for (size_t i = 0; i < steps.size();) {
         size_t j = i;
         while (j < steps.size() && key(steps[j]) == key(steps[i])) ++j;
-        if (steps[i].kernel == K_SELECT_SCATTER && j - i >= kGroupVariantsFrom)
+        if ((steps[i].kernel == K_SELECT_SCATTER || steps[i].kernel == K_SELECT_SCATTER_WAVE) && j - i >= kGroupVariantsFrom)
           std::stable_sort(steps.begin() + (ptrdiff_t)i, steps.begin() + (ptrdiff_t)j,
                            [&](const Step& x, const Step& y) { return variant(x) < variant(y); });
         i = j;
@@ -1105,10 +1130,11 @@ void nbl_plan::finish() {
     while (j < steps.size() && steps[j].level == steps[i].level &&
            (fuse ? kernel_is_fusable(steps[j].kernel) : (steps[j].kernel == steps[i].kernel && steps[j].es == steps[i].es))) {
       const uint32_t op = op_of(steps[j].kernel, steps[j].es) << kOpShift;
-      const uint32_t aux_base = steps[j].kernel == K_SELECT_SCATTER ? dnodes[steps[j].dnode].part_base : 0u;
+      const bool scatter = steps[j].kernel == K_SELECT_SCATTER || steps[j].kernel == K_SELECT_SCATTER_WAVE;
+      const uint32_t aux_base = scatter ? dnodes[steps[j].dnode].part_base : 0u;
       for (uint32_t t = 0; t < steps[j].n_tiles; ++t) {
         tiles.push_back(TileRef{steps[j].dnode, op | (steps[j].tile_begin + t)});
-        tile_aux.push_back(steps[j].kernel == K_SELECT_SCATTER ? aux_base + steps[j].tile_begin + t : 0u);
+        tile_aux.push_back(scatter ? aux_base + steps[j].tile_begin + t : 0u);
       }
       L.alg_bytes += steps[j].alg;
       ++j;
@@ -1206,6 +1232,8 @@ nbl_status nbl_plan_batch(const uint8_t* base, const uint64_t* offsets, const ui
     p->varint_rows = options && options->struct_size >= 8 && options->use_varint_row_count;
     p->fused = !(options && options->struct_size >= 12 && (options->flags & NBL_PLAN_PER_KERNEL_LAUNCHES));
     p->keep_dictionary = options && options->struct_size >= 12 && (options->flags & NBL_PLAN_KEEP_DICTIONARY);
+    p->wave_scatter = !(options && options->struct_size >= 12 && (options->flags & NBL_PLAN_FOUR_WAVE_SCATTER));
+    if (options && options->struct_size >= 16 && options->wave_scatter_min_tiles) p->wave_min_tiles = options->wave_scatter_min_tiles;
     p->layouts.resize(n_chunks);
     for (uint32_t c = 0; c < n_chunks; ++c) {
       if (offsets[c] + sizes[c] < offsets[c]) fail(NBL_ERR_ARGUMENT, "chunk %u: offset + size overflows", c);

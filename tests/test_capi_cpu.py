@@ -164,7 +164,7 @@ def test_fused_and_per_operation_plans_agree_on_layout_and_bytes():
 
     chunks = WL.mixed_table_stripe(stripe=1, rows=3000)
     buf, offs = WL.pack_chunks(chunks)
-    fused, per_op = Plan(buf, offs), Plan(buf, offs, per_kernel=True)
+    fused, per_op = Plan(buf, offs, four_wave_scatter=True), Plan(buf, offs, per_kernel=True, four_wave_scatter=True)
     assert fused.info.out_bytes == per_op.info.out_bytes and fused.info.work_bytes == per_op.info.work_bytes
     for a, b in zip(fused.layouts, per_op.layouts):
         assert bytes(a) == bytes(b)
@@ -175,7 +175,26 @@ def test_fused_and_per_operation_plans_agree_on_layout_and_bytes():
     assert sum(l[4] for l in lf) == sum(l[4] for l in lp) == fused.info.encoded_bytes + fused.info.decoded_bytes
     assert sum(l[2] for l in lf) == sum(l[2] for l in lp)  # same tiles, grouped differently
     assert [l[3] for l in lp] == sorted(l[3] for l in lp)
-    fused.close(); per_op.close()
+    # Rank scatters of sparse selections can go to the one-wave kernel, a launch
+    # of its own behind the fused launch of its level (by default only where a
+    # level has tens of thousands of such tiles): same outputs, same tiles and
+    # bytes, one fused launch per level as before.
+    small = Plan(buf, offs)
+    assert {l[0] for l in small.launches()} <= {"k_level<false>", "k_level<true>"}
+    small.close()
+    dflt = Plan(buf, offs, wave_scatter_min_tiles=1)
+    assert dflt.info.out_bytes == fused.info.out_bytes
+    for a, b in zip(dflt.layouts, fused.layouts):
+        assert bytes(a) == bytes(b)
+    ld = dflt.launches()
+    names = {l[0] for l in ld}
+    assert names <= {"k_level<false>", "k_level<true>", "k_select_scatter_wave<4>", "k_select_scatter_wave<8>"}
+    assert names & {"k_select_scatter_wave<4>", "k_select_scatter_wave<8>"}  # the table has sparse nullable columns
+    assert [l[3] for l in ld] == sorted(l[3] for l in ld)
+    fused_levels = [l[3] for l in ld if l[0].startswith("k_level")]
+    assert fused_levels == sorted(set(fused_levels))
+    assert sum(l[4] for l in ld) == sum(l[4] for l in lf) and sum(l[2] for l in ld) == sum(l[2] for l in lf)
+    fused.close(); per_op.close(); dflt.close()
 
 
 def test_leaf_only_chunks_fill_the_preparatory_levels():
@@ -229,8 +248,9 @@ def test_values_children_resolved_inside_the_rank_scatter():
     nn = int(mask.sum())
 
     def names(enc):
-        p = Plan.from_encodings([enc], per_kernel=True)
-        out = [l[0] for l in p.launches()]
+        # the one-wave kernel takes the scatters that stage few values; what a scatter resolves does not depend on it
+        p = Plan.from_encodings([enc], per_kernel=True, wave_scatter_min_tiles=1)
+        out = [l[0].replace("k_select_scatter_wave", "k_select_scatter") for l in p.launches()]
         p.close()
         return out
 
