@@ -1113,6 +1113,14 @@ void nbl_plan::finish() {
         if ((steps[i].kernel == K_SELECT_SCATTER || steps[i].kernel == K_SELECT_SCATTER_WAVE) && j - i >= kGroupVariantsFrom)
           std::stable_sort(steps.begin() + (ptrdiff_t)i, steps.begin() + (ptrdiff_t)j,
                            [&](const Step& x, const Step& y) { return variant(x) < variant(y); });
+        // Bitmap tiles of SparseBool columns cost in proportion to the positions
+        // they read (a column of 20,000 takes ten rounds of loads, one of 1,000
+        // a single one): the long ones go first, so that the level ends with
+        // short tiles filling the gaps instead of a few long ones running alone.
+        if (steps[i].kernel == K_SPARSE_BITS && j - i >= kGroupVariantsFrom)
+          std::stable_sort(steps.begin() + (ptrdiff_t)i, steps.begin() + (ptrdiff_t)j, [&](const Step& x, const Step& y) {
+            return dnodes[x.dnode].c0.rows / x.n_tiles > dnodes[y.dnode].c0.rows / y.n_tiles;
+          });
         i = j;
       }
     }
