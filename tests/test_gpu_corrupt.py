@@ -20,8 +20,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _decode_expect_device_data(encodings, match):
-    for per_kernel in (False, True):
-        plan = Plan.from_encodings(encodings, per_kernel=per_kernel)
+    # fused and per-operation launches; rank scatters as four-wave tiles and on the one-wave kernel
+    for per_kernel, wave_min in ((False, 0), (True, 0), (False, 1), (True, 1)):
+        plan = Plan.from_encodings(encodings, per_kernel=per_kernel, wave_scatter_min_tiles=wave_min)
         dec = BatchDecoder(plan)
         dec.stage()
         dec.decode()

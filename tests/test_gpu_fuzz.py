@@ -39,8 +39,8 @@ def test_damaged_bytes_never_fault(gpu):
         except (capi.NimbleCorruptError, capi.NimbleUnsupportedError):
             rejected += 1
     assert len(survivors) > 100 and rejected > 0
-    for per_kernel in (False, True):
-        plan = Plan.from_encodings(survivors, per_kernel=per_kernel)
+    for per_kernel, wave_min in ((False, 0), (True, 0), (False, 1)):  # the last: rank scatters on the one-wave kernel
+        plan = Plan.from_encodings(survivors, per_kernel=per_kernel, wave_scatter_min_tiles=wave_min)
         dec = BatchDecoder(plan)
         dec.stage()
         dec.decode()
