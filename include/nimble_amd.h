@@ -258,6 +258,11 @@ const char* nbl_last_error(void);
 /* Library / device introspection: returns the gfx arch string the kernels
  * were built for ("gfx950"). */
 const char* nbl_build_arch(void);
+/* Hash of the library's source files as the build saw them (nimble_amd/build.py
+ * passes it in; "unknown" for a build that did not): lets a caller -- and the
+ * GPU test suite -- tell a library built from other sources than the ones
+ * beside it.  No counterpart in the reference. */
+const char* nbl_build_source_id(void);
 
 #ifdef __cplusplus
 }

@@ -36,6 +36,18 @@ def _stale(target: str, sources) -> bool:
     return any(os.path.getmtime(s) > t for s in sources if os.path.exists(s))
 
 
+def source_id() -> str:
+    """Hash of every source and header the library is built from; compiled into
+    it (nbl_build_source_id), so a test can tell a stale binary."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in _DEVICE_SOURCES + _HEADERS:
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _obj(src: str) -> str:
     return os.path.join(LIB_DIR, "obj", os.path.basename(src) + ".o")
 
@@ -46,13 +58,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
     headers = [os.path.join(CSRC, h) for h in _HEADERS]
     objs = []
     relink = force
+    sid = source_id()
+    sid_path = os.path.join(LIB_DIR, "obj", "source_id.txt")
+    sid_changed = not os.path.exists(sid_path) or open(sid_path).read().strip() != sid
     for name in _DEVICE_SOURCES:
         src = os.path.join(CSRC, name)
         obj = _obj(src)
         objs.append(obj)
-        if force or _stale(obj, [src] + headers):
+        carries_id = name == "nbl_plan.cpp"  # the translation unit that holds nbl_build_source_id()
+        if force or _stale(obj, [src] + headers) or (carries_id and sid_changed):
             cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-Wall",
                    "-Wno-unused-function", "-Wno-pass-failed", "-c", src, "-o", obj]
+            if carries_id:
+                cmd.insert(-4, f'-DNBL_SOURCE_ID="{sid}"')
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.check_call(cmd)
@@ -63,6 +81,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+    with open(sid_path, "w") as f:
+        f.write(sid + "\n")
     return LIB_PATH
 
 

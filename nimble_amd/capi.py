@@ -23,7 +23,7 @@ NBL_ERR_DEVICE_DATA = 5
 EXPORTED_SYMBOLS = (
     "nbl_plan_batch", "nbl_plan_free", "nbl_plan_get_info", "nbl_plan_get_chunk_layout",
     "nbl_split_stream", "nbl_plan_upload", "nbl_decode_batch_device", "nbl_decode_status",
-    "nbl_plan_get_launch", "nbl_last_error", "nbl_build_arch",
+    "nbl_plan_get_launch", "nbl_last_error", "nbl_build_arch", "nbl_build_source_id",
     "nbl_profile_create", "nbl_profile_free", "nbl_decode_batch_profiled", "nbl_profile_collect",
     "nbl_split_stream_ex", "nbl_uncompressed_size", "nbl_uncompress", "nbl_chunk_inflated_size", "nbl_chunk_inflate",
 )
@@ -100,6 +100,7 @@ def lib():
         vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
         L.nbl_last_error.restype = C.c_char_p
         L.nbl_build_arch.restype = C.c_char_p
+        L.nbl_build_source_id.restype = C.c_char_p
         L.nbl_plan_batch.restype = C.c_int
         L.nbl_plan_batch.argtypes = [vp, vp, vp, u32, C.POINTER(NblOptions), C.POINTER(vp)]
         L.nbl_plan_free.argtypes = [vp]

@@ -1192,6 +1192,10 @@ extern "C" {
 const char* nbl_last_error(void) { return g_last_error.c_str(); }
 void nbl_set_last_error(const char* msg) { g_last_error = msg ? msg : ""; }  // for the library's other translation units
 const char* nbl_build_arch(void) { return "gfx950"; }
+#ifndef NBL_SOURCE_ID
+#define NBL_SOURCE_ID "unknown"
+#endif
+const char* nbl_build_source_id(void) { return NBL_SOURCE_ID; }
 
 nbl_status nbl_split_stream_ex(const uint8_t* stream, uint64_t size, uint64_t* offsets, uint64_t* sizes, uint8_t* compression,
                                uint32_t capacity, uint32_t* n_chunks) {

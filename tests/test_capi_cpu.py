@@ -29,6 +29,9 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, sym), f"{sym} is declared in include/nimble_amd.h but not exported"
     assert declared == set(capi.EXPORTED_SYMBOLS)
     assert lib.nbl_build_arch() == b"gfx950"
+    from nimble_amd import build as nb
+
+    assert lib.nbl_build_source_id().decode() == nb.source_id(), "libnimble_amd.so was built from other sources: rebuild"
 
 
 def test_no_oracle_in_product_path():

@@ -25,3 +25,14 @@ def test_golden_vectors_single_chunk_plans(gpu):
     for c in load_cases():
         (r,) = decode_encodings([c["enc"]], varint_rows=c["varint_rows"])
         assert_matches(c, r.values, r.nulls, r.non_null, c["name"])
+
+
+def test_library_is_built_from_the_sources_beside_it(gpu):
+    """The GPU box runs the prebuilt library that travels with the tree: its
+    arch and the hash of the sources it was compiled from must match."""
+    from nimble_amd import build as nb
+    from nimble_amd import capi
+
+    lib = capi.lib()
+    assert lib.nbl_build_arch() == b"gfx950"
+    assert lib.nbl_build_source_id().decode() == nb.source_id()
