@@ -1307,27 +1307,30 @@ __device__ __forceinline__ void sparse_bits_tile(const KArgs& a, const NodeDesc&
     uint32_t* bits32 = reinterpret_cast<uint32_t*>(s_bits);
     // Eight positions per thread and round, and the next round's loads are
     // issued before this round's positions are used: a column of R rounds
-    // waits for about one memory round trip instead of R.
+    // waits for about one memory round trip instead of R.  Dense columns are
+    // bound by the instructions per position, so all of it is 32-bit work on
+    // top of a scalar base: positions relative to `lo` (a view), rows relative
+    // to the tile, one unsigned compare for "inside the tile".
     constexpr uint32_t PPT = 8;
+    const uint32_t tile_row0 = (uint32_t)p0, span = (uint32_t)(p1 - p0);
+    const uint32_t cnt = hi > lo ? hi - lo : 0u;       // positions of this tile (<= its rows)
+    const auto list = rd.view(lo);
     uint32_t pos[PPT], nxt[PPT];
-    auto fetch = [&](uint32_t (&dst)[PPT], uint32_t j0) {
+    auto fetch = [&](uint32_t (&dst)[PPT], uint32_t i0) {  // positions lo + i0 + u * kBlock
 #pragma unroll
       for (uint32_t u = 0; u < PPT; ++u) {
-        const uint32_t j = j0 + u * kBlock;
-        dst[u] = rd.get(j < hi ? j : hi - 1);
+        const uint32_t i = i0 + u * kBlock;
+        dst[u] = list.at(i < cnt ? i : cnt - 1);
       }
     };
-    if (lo < hi) fetch(pos, lo + threadIdx.x);
-    for (uint32_t r0 = lo; r0 < hi; r0 += PPT * kBlock) {  // r0: workgroup uniform
-      const uint32_t j0 = r0 + threadIdx.x;
-      if (r0 + PPT * kBlock < hi) fetch(nxt, j0 + PPT * kBlock);
+    if (cnt) fetch(pos, threadIdx.x);
+    for (uint32_t r0 = 0; r0 < cnt; r0 += PPT * kBlock) {  // r0: workgroup uniform
+      const uint32_t i0 = r0 + threadIdx.x;
+      if (r0 + PPT * kBlock < cnt) fetch(nxt, i0 + PPT * kBlock);
 #pragma unroll
       for (uint32_t u = 0; u < PPT; ++u) {
-        const uint32_t j = j0 + u * kBlock;
-        if (j < hi && pos[u] >= p0 && pos[u] < p1) {
-          const uint32_t q = (uint32_t)(pos[u] - p0);
-          atomicOr(&bits32[q >> 5], 1u << (q & 31));
-        }
+        const uint32_t q = pos[u] - tile_row0;             // wraps for a position in front of the tile
+        if (i0 + u * kBlock < cnt && q < span) atomicOr(&bits32[q >> 5], 1u << (q & 31));
       }
 #pragma unroll
       for (uint32_t u = 0; u < PPT; ++u) pos[u] = nxt[u];
