@@ -41,7 +41,8 @@ def decode_and_check(O, chunks, stride=1):
             assert_chunk_equal(slice_chunk(host, lay), oracle_chunk(O, enc), label)
     info = plan.info
     assert int(info.total_rows) == rows
-    res = dict(n_chunks=int(info.n_chunks), n_launches=int(info.n_launches), n_nodes=int(info.n_nodes), rows=rows)
+    res = dict(n_chunks=int(info.n_chunks), n_launches=int(info.n_launches), n_nodes=int(info.n_nodes), rows=rows,
+               kernels=[l[0] for l in plan.launches()])
     plan.close()
     return res
 
@@ -86,3 +87,6 @@ def test_wide_table_stripe_full_size(gpu, oracle):
     r = decode_and_check(oracle, chunks)
     assert r["n_chunks"] == 5000 and r["rows"] == 5000 * 100_000
     assert r["n_launches"] <= 40
+    # a stripe of this shape has ~10^5 sparse rank-scatter tiles: they run on the one-wave kernel,
+    # and its columns of 100,000 rows need no scan level (selection bitmaps, then the scatters)
+    assert "k_select_scatter_wave<4>" in r["kernels"] and r["n_launches"] == 3
