@@ -113,8 +113,9 @@ constexpr size_t kDenseSparseMaxChunks = 512;
 // built by one workgroup: two rounds of loads in a small batch, sixteen where
 // thousands of other tiles cover the wait.
 constexpr uint32_t kWholeMaxPositions = 4096, kWholeMaxPositionsBatch = 32768;
-// Tiles of one level and element size from which the one-wave rank scatter gets its own launch.
-constexpr uint64_t kWaveLaunchMinTiles = 32768;
+// Rank-scatter tiles of one level (16 KiB of output each) from which the one-wave
+// kernel gets its own launch; a launch of one element size needs an eighth of that.
+constexpr uint64_t kWaveLaunchMinTiles = 65536;
 
 struct Step {
   int level;
@@ -1067,15 +1068,24 @@ void nbl_plan::finish() {
   for (Step& st : steps)
     if (st.chunk >= 0) st.alg = chunk_alg[(size_t)st.chunk];
   {
-    // The one-wave rank scatter is a launch of its own: worth it only where a
-    // level has enough of its tiles to fill the chip several times over (a
-    // 5,000-column stripe has ~10^5); fewer run as four-wave tiles inside the
-    // level's fused launch, where other work covers their waits.
-    std::vector<uint64_t> wave_tiles((size_t)(last_level + 1) * 4, 0);
-    for (const Step& st : steps)
+    // The one-wave rank scatter is a launch of its own, and what it buys is
+    // tolerance to memory latency: it pays where a level's rank scatters write
+    // more than the memory-side cache and the inputs of the step can hold
+    // between them, so that every dependent load of a tile goes to memory under
+    // the level's own write stream.  Measured on stripes of 100,000-row sparse
+    // float columns: from 78,000 rank-scatter tiles (1.3 GB of output) up the
+    // one-wave launch wins (by 13 / 20 / 20% at 94,000 / 109,000 / 125,000), at
+    // 62,500 it loses 10%, at 4,600 (a 100-column stripe) 7%.  Fewer tiles run
+    // as four-wave tiles inside the level's fused launch.
+    std::vector<uint64_t> scatter_tiles((size_t)last_level + 1, 0), wave_tiles((size_t)(last_level + 1) * 4, 0);
+    for (const Step& st : steps) {
+      if (st.kernel == K_SELECT_SCATTER || st.kernel == K_SELECT_SCATTER_WAVE) scatter_tiles[(size_t)st.level] += st.n_tiles;
       if (st.kernel == K_SELECT_SCATTER_WAVE) wave_tiles[(size_t)st.level * 4 + es_slot(st.es)] += st.n_tiles;
+    }
     for (Step& st : steps)
-      if (st.kernel == K_SELECT_SCATTER_WAVE && wave_tiles[(size_t)st.level * 4 + es_slot(st.es)] < wave_min_tiles)
+      if (st.kernel == K_SELECT_SCATTER_WAVE &&
+          (scatter_tiles[(size_t)st.level] < wave_min_tiles ||
+           wave_tiles[(size_t)st.level * 4 + es_slot(st.es)] * 8 < wave_min_tiles))
         st.kernel = K_SELECT_SCATTER;
   }
   if (fused && last_level > 0) spread_free_steps(last_level);
