@@ -344,3 +344,32 @@ def test_chunk_offsets_that_overflow_are_refused():
     plan = C.c_void_p()
     st = capi.lib().nbl_plan_batch(buf.ctypes.data, offs.ctypes.data, sizes.ctypes.data, 1, None, C.byref(plan))
     assert st == capi.NBL_ERR_ARGUMENT and b"overflows" in capi.lib().nbl_last_error()
+
+
+def test_one_wave_scatter_needs_a_level_full_of_rank_scatters():
+    """The one-wave kernel is launched for a level whose rank scatters (of either
+    kind) reach wave_scatter_min_tiles and whose eligible tiles of one element
+    size are at least an eighth of that; below either bound they stay four-wave
+    tiles inside the fused launch."""
+    rng = np.random.default_rng(3)
+    n = 60_000  # 15 tiles of 4096 float rows per column
+    cols = []
+    for c in range(8):
+        mask = rng.random(n) < 0.05
+        vals = rng.integers(0, 1 << 30, int(mask.sum())).astype(np.float32)
+        cols.append(E.encode_nullable(E.Nullable(data=E.Trivial(), nulls=E.SparseBool()), vals, mask, W.FLOAT))
+    dense_mask = rng.random(n) < 0.9   # a dense selection: never on the one-wave kernel, but it counts for the level
+    dense = E.encode_nullable(E.Nullable(data=E.Trivial(), nulls=E.Trivial()),
+                              rng.integers(0, 1 << 30, int(dense_mask.sum())).astype(np.float32), dense_mask, W.FLOAT)
+
+    def wave_tiles(encs, min_tiles):
+        p = Plan.from_encodings(encs, wave_scatter_min_tiles=min_tiles)
+        t = sum(l[2] for l in p.launches() if l[0].startswith("k_select_scatter_wave"))
+        p.close()
+        return t
+
+    assert wave_tiles(cols, 120) == 8 * 15          # 120 rank-scatter tiles in the level: exactly the bound
+    assert wave_tiles(cols, 121) == 0
+    assert wave_tiles(cols + [dense], 135) == 8 * 15   # the dense column's 15 tiles count for the level
+    assert wave_tiles(cols[:1] + [dense] * 9, 150) == 0   # 15 eligible tiles < 150 / 8
+    assert wave_tiles(cols[:2] + [dense] * 8, 150) == 30
