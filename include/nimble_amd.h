@@ -57,8 +57,8 @@ typedef struct nbl_options {
   uint32_t flags;                  /* NBL_PLAN_* (no counterpart in the reference) */
   uint32_t wave_scatter_min_tiles; /* rank-scatter tiles (16 KiB of output each) of one cascade level from
                                     * which the one-wave kernel gets a launch of its own (fewer run inside
-                                    * the level's fused launch); 0 = the library's default (65536, about
-                                    * 1 GB of scattered output).  Read when struct_size >= 16.
+                                    * the level's fused launch); 0 = the library's default (32768, about
+                                    * 0.5 GB of scattered output).  Read when struct_size >= 16.
                                     * No counterpart in the reference. */
 } nbl_options;
 

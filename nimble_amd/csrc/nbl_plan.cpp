@@ -115,7 +115,7 @@ constexpr size_t kDenseSparseMaxChunks = 512;
 constexpr uint32_t kWholeMaxPositions = 4096, kWholeMaxPositionsBatch = 32768;
 // Rank-scatter tiles of one level (16 KiB of output each) from which the one-wave
 // kernel gets its own launch; a launch of one element size needs an eighth of that.
-constexpr uint64_t kWaveLaunchMinTiles = 65536;
+constexpr uint64_t kWaveLaunchMinTiles = 32768;
 
 struct Step {
   int level;
@@ -1069,14 +1069,16 @@ void nbl_plan::finish() {
     if (st.chunk >= 0) st.alg = chunk_alg[(size_t)st.chunk];
   {
     // The one-wave rank scatter is a launch of its own, and what it buys is
-    // tolerance to memory latency: it pays where a level's rank scatters write
-    // more than the memory-side cache and the inputs of the step can hold
-    // between them, so that every dependent load of a tile goes to memory under
-    // the level's own write stream.  Measured on stripes of 100,000-row sparse
-    // float columns: from 78,000 rank-scatter tiles (1.3 GB of output) up the
-    // one-wave launch wins (by 13 / 20 / 20% at 94,000 / 109,000 / 125,000), at
-    // 62,500 it loses 10%, at 4,600 (a 100-column stripe) 7%.  Fewer tiles run
-    // as four-wave tiles inside the level's fused launch.
+    // tolerance to memory latency: it pays where the dependent loads of a tile
+    // go to memory under the level's own write stream.  Measured on stripes of
+    // 100,000-row sparse float columns: decoded once with cold caches (a reader's
+    // case) the one-wave launch is level at 7,500 rank-scatter tiles and wins by
+    // 8 / 11% at 31,000 / 62,500; decoded over and over, so that a small stripe's
+    // inputs stay in the memory-side cache, it loses 10% at 62,500, breaks even
+    // at 78,000 (1.3 GB of output per step) and wins by 13-20% from 94,000 up.
+    // A launch of a few thousand tiles loses either way (a 100-column stripe:
+    // 3-7%), hence the second bound per element size.  Fewer tiles run as
+    // four-wave tiles inside the level's fused launch.
     std::vector<uint64_t> scatter_tiles((size_t)last_level + 1, 0), wave_tiles((size_t)(last_level + 1) * 4, 0);
     for (const Step& st : steps) {
       if (st.kernel == K_SELECT_SCATTER || st.kernel == K_SELECT_SCATTER_WAVE) scatter_tiles[(size_t)st.level] += st.n_tiles;
