@@ -1343,17 +1343,23 @@ __device__ __forceinline__ void sparse_bits_tile(const KArgs& a, const NodeDesc&
   // (NF_EMIT_PARTS: part_base / aux2 are the parent's, NF_INVERT_SEL = it
   // selects the zero bits), so no counting pass reads the bitmap back.
   const bool emit = (nd.flags & NF_EMIT_PARTS) != 0, zeros = (nd.flags & NF_INVERT_SEL) != 0;
+  // The words are stored after the partials are out: a workgroup barrier waits
+  // for every store issued before it to be acknowledged, and the partials'
+  // reduction has barriers -- stored first, the 12.5 KB of a column would hold
+  // the workgroup (and its slot on the CU) for a trip to memory in the middle.
   uint32_t cnt[WPT];
+  uint64_t words[WPT];
 #pragma unroll
   for (uint32_t u = 0; u < WPT; ++u) {
     const uint64_t w = (uint64_t)tile * W + u * kBlock + threadIdx.x;
     cnt[u] = 0;
+    words[u] = 0;
     if (w * 64 < rows) {
       uint64_t v = s_bits[u * kBlock + threadIdx.x];
       if (!(nd.flags & NF_SPARSE_VALUE)) v = ~v;
       const uint64_t m = w * 64 + 64 > rows ? wmask((uint32_t)(rows - w * 64)) : ~0ull;
       v &= m;
-      dst[w] = v;
+      words[u] = v;
       cnt[u] = (uint32_t)__popcll(zeros ? ~v & m : v);
     }
   }
@@ -1361,6 +1367,11 @@ __device__ __forceinline__ void sparse_bits_tile(const KArgs& a, const NodeDesc&
     if (emit) emit_scanned_partials<WPT>(a, nd.part_base, nd.n_parts, nd.total_idx, (uint32_t)(nd.aux2 >> 6), cnt, reinterpret_cast<uint32_t*>(smem));
   } else {
     if (emit) emit_rank_partials<WPT>(a, nd.part_base, (uint32_t)(nd.aux2 >> 6), rows, tile, cnt, reinterpret_cast<uint32_t*>(smem));
+  }
+#pragma unroll
+  for (uint32_t u = 0; u < WPT; ++u) {
+    const uint64_t w = (uint64_t)tile * W + u * kBlock + threadIdx.x;
+    if (w * 64 < rows) dst[w] = words[u];
   }
 }
 
