@@ -106,6 +106,11 @@ enum NodeFlags : uint32_t {
                              // When it emits rank partials (NF_EMIT_PARTS, or always for K_REDUCE_POPC) it writes them
                              // already scanned, with the node's totals (n_parts / total_idx are the parent's), so the
                              // parent needs no scan step: one launch level less for columns of up to 131072 rows
+  NF_SELF_SCAN = 1u << 12,   // K_REDUCE_SUM / K_RLE_ENDS / K_STRING_VIEWS: no K_SCAN_TILES step runs for the node. Every
+                             // consumer tile adds up the tile sums in front of its own (parts[] stays as K_REDUCE_SUM
+                             // wrote it), its last tile writes the node's total, and the node's flag word is cleared by
+                             // K_REDUCE_SUM's first tile -- or, for a node of one tile, which has no K_REDUCE_SUM step
+                             // either, written by that tile
   NF_FRAME_BITS = 1u << 4,   // K_FRAME_UNPACK: FOR (u64 bit offsets, no raw marker) instead of
                              // BlockBitPacking (u32 byte offsets, width 255 = raw block)
 };
@@ -177,6 +182,7 @@ constexpr uint32_t kSparseTileWords = 1024;  // words per tile of the positions 
 constexpr uint32_t kSparseTileRows = kSparseTileWords * 64;
 constexpr uint32_t kWholeTileWords = 2048;   // words of a bitmap that one workgroup builds or counts alone (NF_WHOLE_NODE)
 constexpr uint32_t kWholeTileRows = kWholeTileWords * 64;
+constexpr uint32_t kSelfScanMaxTiles = 1024;  // NF_SELF_SCAN: at most this many tile sums per node (2M lengths)
 constexpr uint32_t kVarintTile = 4096;      // encoded bytes per varint tile
 // Rows per tile of the rank-scatter (Nullable / MainlyConstant) of `es`-byte elements.
 constexpr uint32_t select_tile_rows(uint32_t es) { return kTileBytes / es; }

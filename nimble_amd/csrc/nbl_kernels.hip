@@ -827,7 +827,19 @@ __device__ __forceinline__ void body_reduce_sum(const KArgs& a, const NodeDesc& 
     for (uint32_t j = 0; j < 8; ++j) s += r0 + j < tn ? v[j] : 0u;
   });
   const uint32_t tot = block_sum(s, tmp);
-  if (threadIdx.x == 0) a.parts[nd.part_base + tile] = tot;
+  if (threadIdx.x == 0) {
+    a.parts[nd.part_base + tile] = tot;
+    if (tile == 0 && (nd.flags & NF_SELF_SCAN)) a.totals[nd.total_idx + 1] = 0;  // the node's flag word, as K_SCAN_TILES would
+  }
+}
+
+// NF_SELF_SCAN: the sum of the node's tile sums in front of tile `tile` (what
+// K_SCAN_TILES would have left in parts[tile]); at most kSelfScanMaxTiles of
+// them, written by an earlier launch.  Every thread calls.
+__device__ __forceinline__ uint32_t sum_of_tiles_before(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint32_t* tmp) {
+  uint32_t s = 0;
+  for (uint32_t i = threadIdx.x; i < tile; i += kBlock) s += a.parts[nd.part_base + i];
+  return block_sum(s, tmp);
 }
 
 // Sum of `s` over the aligned group of `sub` consecutive threads (sub = 32, 64,
@@ -1006,8 +1018,11 @@ __device__ __forceinline__ void body_rle_ends(const KArgs& a, const NodeDesc& nd
     s += len;
     v[j] = s;
   }
+  const bool self_scan = (nd.flags & NF_SELF_SCAN) != 0;
+  const uint32_t before = self_scan ? sum_of_tiles_before(a, nd, tile, tmp) : sload32(a.parts + nd.part_base + tile);
   uint32_t total;
-  const uint32_t ex = block_excl_scan(s, tmp, total) + sload32(a.parts + nd.part_base + tile);
+  const uint32_t ex = block_excl_scan(s, tmp, total) + before;
+  if (self_scan && tile + 1 == nd.n_parts && threadIdx.x == 0) a.totals[nd.total_idx] = before + total;
   uint32_t* ends = reinterpret_cast<uint32_t*>(a.work + nd.aux_off);
   if (e0 + 8 <= n) {
     *reinterpret_cast<u32x4*>(ends + e0) = make_u32x4(v[0] + ex, v[1] + ex, v[2] + ex, v[3] + ex);
@@ -1017,7 +1032,12 @@ __device__ __forceinline__ void body_rle_ends(const KArgs& a, const NodeDesc& nd
     for (uint32_t j = 0; j < 8; ++j)
       if (e0 + j < n) ends[e0 + j] = v[j] + ex;
   }
-  if (__ballot(zero) != 0 && lane_id() == 0) atomicOr(&a.totals[nd.total_idx + 1], 1u);
+  if (self_scan && nd.n_parts == 1) {  // the node's only tile: it writes the flag word itself
+    const int any_zero = __syncthreads_or(zero);
+    if (threadIdx.x == 0) a.totals[nd.total_idx + 1] = any_zero ? 1u : 0u;
+  } else if (__ballot(zero) != 0 && lane_id() == 0) {
+    atomicOr(&a.totals[nd.total_idx + 1], 1u);
+  }
   // first_run[t] = the run that holds row t * tile_rows, for every output tile t:
   // run i covers rows [start, end), so it is the first run of every tile whose
   // first row falls inside it.  Spares the expand step a search per tile.
@@ -2411,8 +2431,10 @@ __device__ __forceinline__ void body_string_views(const KArgs& a, const NodeDesc
     len[j] = e0 + j < n ? len[j] : 0;
     s += len[j];
   }
+  const bool self_scan = (nd.flags & NF_SELF_SCAN) != 0;
+  const uint32_t before = self_scan ? sum_of_tiles_before(a, nd, tile, tmp) : sload32(a.parts + nd.part_base + tile);
   uint32_t total;
-  uint32_t off = block_excl_scan(s, tmp, total) + sload32(a.parts + nd.part_base + tile) + (uint32_t)nd.aux;
+  uint32_t off = block_excl_scan(s, tmp, total) + before + (uint32_t)nd.aux;
   uint64_t* dst = reinterpret_cast<uint64_t*>(self_ptr(nd, a));
   uint64_t v[8];
 #pragma unroll
@@ -2429,7 +2451,11 @@ __device__ __forceinline__ void body_string_views(const KArgs& a, const NodeDesc
     for (uint32_t j = 0; j < 8; ++j)
       if (e0 + j < n) dst[e0 + j] = v[j];
   }
-  if (tile == 0 && threadIdx.x == 0 && sload32(a.totals + nd.total_idx) > nd.aux2) atomicOr(a.status, ST_STRING_BYTES);
+  if (self_scan) {  // the last tile knows the sum of all lengths
+    if (tile + 1 == nd.n_parts && threadIdx.x == 0 && (uint64_t)before + total > nd.aux2) atomicOr(a.status, ST_STRING_BYTES);
+  } else if (tile == 0 && threadIdx.x == 0 && sload32(a.totals + nd.total_idx) > nd.aux2) {
+    atomicOr(a.status, ST_STRING_BYTES);
+  }
 }
 
 // -------------------------------------------------------------- K_COPY_BYTES

@@ -616,11 +616,17 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
         d.rows = rows; d.aux = rel; d.aux2 = nn.payload_bytes;
         const uint32_t nt = div_up32(rows, kScanTile);
         alloc_scan(d, nt);
+        // up to kSelfScanMaxTiles tile sums: the view tiles add up the sums in front
+        // of their own instead of a scan step doing it (one launch level less); a
+        // column of one tile needs no sums at all
+        const bool self_scan = nt <= kSelfScanMaxTiles;
+        if (self_scan) d.flags |= NF_SELF_SCAN;
         const uint32_t dn = add_dnode(d);
-        add_step(lvl, K_REDUCE_SUM, 4, dn, nt);
-        add_step(lvl + 1, K_SCAN_TILES, 0, dn, 1, true);
-        add_step(lvl + 2, K_STRING_VIEWS, 8, dn, nt);
-        nn.ref = d.self; nn.ready = lvl + 3;
+        int at = lvl;
+        if (nt > 1 || !self_scan) add_step(at++, K_REDUCE_SUM, 4, dn, nt);
+        if (!self_scan) add_step(at++, K_SCAN_TILES, 0, dn, 1, true);
+        add_step(at++, K_STRING_VIEWS, 8, dn, nt);
+        nn.ref = d.self; nn.ready = at;
       } else if (nn.is_bool) {
         ColRef r{}; r.kind = COL_BITS_RAW; r.off = nn.payload_off; r.rows = rows;
         nn.ref = r; nn.ready = 0;
@@ -691,22 +697,28 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
         if (!nn.fused_runs) d.self = mat_ref(es);
         d.c1 = C(1).ref;
       }
+      // up to kSelfScanMaxTiles tile sums: the run-end tiles add up the sums in
+      // front of their own instead of a scan step doing it (one launch level less);
+      // a column of one tile of runs needs no sums at all
+      const bool self_scan = nt <= kSelfScanMaxTiles;
+      if (self_scan) d.flags |= NF_SELF_SCAN;
       const uint32_t dn = add_dnode(d, /*aux_work=*/true);
-      add_step(lvl, K_REDUCE_SUM, 4, dn, nt);
-      add_step(lvl + 1, K_SCAN_TILES, 0, dn, 1, true);
-      add_step(lvl + 2, K_RLE_ENDS, 4, dn, nt);
+      int at = lvl;
+      if (nt > 1 || !self_scan) add_step(at++, K_REDUCE_SUM, 4, dn, nt);
+      if (!self_scan) add_step(at++, K_SCAN_TILES, 0, dn, 1, true);
+      add_step(at++, K_RLE_ENDS, 4, dn, nt);
       if (nn.fused_runs) {
         // the parent expands: hand it the run ends (a work array, rebased with the
         // other intermediates), the run values and the totals slot
         nn.ends_ref.kind = COL_MAT_WORK; nn.ends_ref.off = d.aux_off; nn.ends_ref.rows = rows; nn.ends_ref.es = 4;
         nn.sel_total_idx = d.total_idx;
         nn.ref = d.c1; nn.ref.rows = R;
-        nn.ready = lvl + 3;
+        nn.ready = at;
         break;
       }
-      if (nn.is_bool) add_step(lvl + 3, K_RLE_EXPAND_BOOL, 0, dn, div_up32(rows, kBitTileRows));
-      else add_step(lvl + 3, K_RLE_EXPAND, es, dn, div_up32(rows, tile_rows));
-      nn.ref = d.self; nn.ready = lvl + 4;
+      if (nn.is_bool) add_step(at, K_RLE_EXPAND_BOOL, 0, dn, div_up32(rows, kBitTileRows));
+      else add_step(at, K_RLE_EXPAND, es, dn, div_up32(rows, tile_rows));
+      nn.ref = d.self; nn.ready = at + 1;
       break;
     }
     case ET_SPARSEBOOL: {

@@ -210,11 +210,11 @@ def test_leaf_only_chunks_fill_the_preparatory_levels():
     deep = [E.encode(E.RLE(), np.repeat(rng.integers(0, 50, n // 20), 20).astype(np.int64), W.INT64)]
     p = Plan.from_encodings(leaf + deep)
     launches = p.launches()
-    assert len(launches) == 4  # reduce, scan, run ends, expand
+    assert len(launches) == 3  # tile sums, run ends (each tile adds up the sums in front of its own), expand
     tiles = [l[2] for l in launches]
     assert min(tiles) > 100 and max(tiles) < 3 * min(tiles), tiles
     only_deep = Plan.from_encodings(deep)
-    assert [l[2] for l in only_deep.launches()][1] == 1  # the scan level alone is one workgroup
+    assert [l[2] for l in only_deep.launches()][:2] == [10, 10]  # 20,000 runs: ten tiles of sums, ten of run ends
     p.close(); only_deep.close()
 
 
@@ -233,10 +233,12 @@ def test_rank_counting_is_placed_at_the_bitmap_level():
     for name, _, _, lvl, _ in p.launches():
         level.setdefault(name, lvl)
     assert level["k_reduce_popc"] == level["k_reduce_sum"] == 0
-    assert "k_rle_expand<8>" not in level and level["k_rle_ends"] == 2 and level["k_select_scatter<8>"] == 3
+    # the run-end tiles add up the tile sums themselves (no scan step for the runs); the ranks still have theirs
+    assert "k_rle_expand<8>" not in level and level["k_rle_ends"] == 1 and level["k_select_scatter<8>"] == 2
+    assert level["k_scan_tiles"] == 1
     p.close()
     fused = Plan.from_encodings([enc])
-    assert int(fused.info.n_launches) == 4
+    assert int(fused.info.n_launches) == 3
     fused.close()
 
 
@@ -279,7 +281,11 @@ def test_bool_rle_root_expands_to_bytes_without_a_bitmap_step():
     expansion; under a Nullable it stays a bitmap for the select step."""
     b = np.repeat(np.arange(500) & 1, 77).astype(bool)
     p = Plan.from_encodings([E.encode(E.RLE(), b, W.BOOL)], per_kernel=True)
-    assert [l[0] for l in p.launches()] == ["k_reduce_sum", "k_scan_tiles", "k_rle_ends", "k_rle_expand_bool"]
+    assert [l[0] for l in p.launches()] == ["k_rle_ends", "k_rle_expand_bool"]  # 500 runs: one tile, no sums to add up
+    p.close()
+    many = np.repeat(np.arange(5000) & 1, 7).astype(bool)                      # 5,000 runs: three tiles
+    p = Plan.from_encodings([E.encode(E.RLE(), many, W.BOOL)], per_kernel=True)
+    assert [l[0] for l in p.launches()] == ["k_reduce_sum", "k_rle_ends", "k_rle_expand_bool"]
     p.close()
     mask = np.random.default_rng(9).random(60_000) < 0.5
     enc = E.encode_nullable(E.Nullable(data=E.RLE(), nulls=E.Trivial()), b[: int(mask.sum())], mask, W.BOOL)
