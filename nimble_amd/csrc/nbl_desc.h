@@ -106,7 +106,7 @@ enum NodeFlags : uint32_t {
                              // When it emits rank partials (NF_EMIT_PARTS, or always for K_REDUCE_POPC) it writes them
                              // already scanned, with the node's totals (n_parts / total_idx are the parent's), so the
                              // parent needs no scan step: one launch level less for columns of up to 131072 rows
-  NF_SELF_SCAN = 1u << 12,   // K_REDUCE_SUM / K_RLE_ENDS / K_STRING_VIEWS: no K_SCAN_TILES step runs for the node. Every
+  NF_SELF_SCAN = 1u << 12,   // K_REDUCE_SUM / K_RLE_ENDS / K_STRING_VIEWS / K_VARINT_DECODE: no K_SCAN_TILES step runs for the node. Every
                              // consumer tile adds up the tile sums in front of its own (parts[] stays as K_REDUCE_SUM
                              // wrote it), its last tile writes the node's total, and the node's flag word is cleared by
                              // K_REDUCE_SUM's first tile -- or, for a node of one tile, which has no K_REDUCE_SUM step

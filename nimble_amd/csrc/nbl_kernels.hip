@@ -2374,9 +2374,14 @@ __device__ __forceinline__ void body_varint_decode(const KArgs& a, const NodeDes
     s_start[k++] = (uint16_t)(o0 + j);
   }
   __syncthreads();
-  if (tile == 0 && threadIdx.x == 0 && sload32(a.totals + nd.total_idx) < nd.rows) atomicOr(a.status, ST_VARINT_COUNT);
   // pass 2
-  const uint64_t rank0 = sload32(a.parts + nd.part_base + tile);
+  const bool self_scan = (nd.flags & NF_SELF_SCAN) != 0;
+  const uint64_t rank0 = self_scan ? sum_of_tiles_before(a, nd, tile, tmp) : sload32(a.parts + nd.part_base + tile);
+  if (self_scan) {  // the last tile knows how many values the payload holds
+    if (tile + 1 == nd.n_parts && threadIdx.x == 0 && rank0 + count < rows) atomicOr(a.status, ST_VARINT_COUNT);
+  } else if (tile == 0 && threadIdx.x == 0 && sload32(a.totals + nd.total_idx) < nd.rows) {
+    atomicOr(a.status, ST_VARINT_COUNT);
+  }
   for (uint32_t i = threadIdx.x; i < count; i += kBlock) {
     if (rank0 + i >= rows) break;
     const uint32_t off = s_start[i];

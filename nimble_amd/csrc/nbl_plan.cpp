@@ -654,11 +654,16 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       d.rows = rows; d.aux2 = nn.payload_bytes;
       const uint32_t nt = div_up32(nn.payload_bytes, kVarintTile);
       alloc_scan(d, nt);
+      // (as for run ends and string views: the decode tiles add up the tile
+      // counts in front of their own, a payload of one tile needs no counts)
+      const bool self_scan = nt <= kSelfScanMaxTiles;
+      if (self_scan) d.flags |= NF_SELF_SCAN;
       const uint32_t dn = add_dnode(d);
-      add_step(lvl, K_REDUCE_VARINT, 0, dn, nt);
-      add_step(lvl + 1, K_SCAN_TILES, 0, dn, 1, true);
-      add_step(lvl + 2, K_VARINT_DECODE, es, dn, nt);
-      nn.ref = d.self; nn.ready = lvl + 3;
+      int at = lvl;
+      if (nt > 1 || !self_scan) add_step(at++, K_REDUCE_VARINT, 0, dn, nt);
+      if (!self_scan) add_step(at++, K_SCAN_TILES, 0, dn, 1, true);
+      add_step(at++, K_VARINT_DECODE, es, dn, nt);
+      nn.ref = d.self; nn.ready = at;
       break;
     }
     case ET_RLE: {

@@ -137,3 +137,26 @@ def test_more_than_1024_tiles_of_sums_keep_the_scan_step(gpu, oracle):
     names = _names([rle, strs])
     assert names.count("k_scan_tiles") == 2
     check_parity(oracle, [rle, strs])
+
+
+def test_varints_in_one_tile_several_tiles_and_behind_a_scan_step(gpu, oracle):
+    """Varint payloads of one 4 KiB tile (no counts), of several (the decode tiles
+    add up the counts in front of their own) and of more than 1,024 (a scan step)."""
+    rng = np.random.default_rng(56)
+    small = E.encode(E.Varint(), rng.integers(0, 1 << 20, 900).astype(np.uint32), W.INT32)
+    several = E.encode(E.Varint(), rng.integers(0, 1 << 40, 60_000).astype(np.uint64), W.INT64)
+    big = E.encode(E.Varint(), rng.integers(128, 1 << 14, 2_200_000).astype(np.uint32), W.INT32)  # two bytes each: 1,075 tiles
+    assert _names([small]) == ["k_varint_decode<4>"]
+    assert _names([several]) == ["k_reduce_varint", "k_varint_decode<8>"]
+    assert _names([big]) == ["k_reduce_varint", "k_scan_tiles", "k_varint_decode<4>"]
+    check_parity(oracle, [small, several, big])
+    _decode_twice(oracle, [small, several])
+    for enc, cut in ((small, 40), (several, 3000)):  # fewer varints than rows: the last tile reports it
+        plan = Plan.from_encodings([enc[: len(enc) - cut]])
+        dec = BatchDecoder(plan)
+        dec.stage()
+        dec.decode()
+        with pytest.raises(capi.NimbleError, match="fewer varints") as ei:
+            dec.status()
+        assert ei.value.status == capi.NBL_ERR_DEVICE_DATA
+        plan.close()
