@@ -1914,7 +1914,13 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
 // in flight for the same bytes, waves and instructions.  No barrier but the
 // wave's own; the four-wave body stays for dense selections, whose staged
 // values need its 16 KiB of LDS, and for the Dictionary / RLE values children.
-constexpr uint32_t kWaveBitsOff = kWaveStageBytes + 16;             // 64 outer words, up to 128 inner ones, a window's slack
+// The stage holds what stage_load() copies for kWaveStageBytes of values: up to
+// one more byte when the first value starts inside a byte, up to 15 bytes in
+// front of it (the copy starts 16-byte aligned), the window's fifth dword, and
+// the round-up to whole 16-byte vectors.
+constexpr uint32_t kWaveStageVecs = (15 + (kWaveStageBytes + 1) + 4 + 15) >> 4;
+constexpr uint32_t kWaveBitsOff = kWaveStageVecs * 16;              // 64 outer words, up to 128 inner ones, a window's slack
+static_assert(kWaveStageVecs <= 3 * kWaveBlock, "StageRegs<3> of a 64-thread workgroup cover the stage");
 constexpr uint32_t kWaveBitsBytes = 192 * 8 + 16;
 constexpr uint32_t kWavePrefOff = kWaveBitsOff + kWaveBitsBytes;    // 384 16-bit prefixes (one per dword of bits)
 constexpr uint32_t kWaveDepOff = kWavePrefOff + 384 * 2;            // deposit table of the nested selection

@@ -141,3 +141,44 @@ def test_mainly_constant_root(gpu, oracle):
             encs.append(E.encode(E.MainlyConstant(is_common=E.SparseBool(), other=E.Trivial()), v, dt))
             encs.append(E.encode(E.MainlyConstant(is_common=E.Trivial(), other=E.FixedBitWidth()), v, dt))
     check_parity(oracle, encs)
+
+
+def _mask_with_counts(rng, tile_rows, counts):
+    """A selection whose tile t (of tile_rows rows) selects exactly counts[t] rows."""
+    mask = np.zeros(tile_rows * len(counts), dtype=bool)
+    for t, c in enumerate(counts):
+        mask[t * tile_rows + rng.choice(tile_rows, c, replace=False)] = True
+    return mask
+
+
+def test_tiles_that_fill_the_stage_exactly_at_every_alignment(gpu, oracle):
+    """Tiles whose selected values fill the one-wave kernel's stage to the last
+    byte (608 4-byte / 304 8-byte values; 1024 values of 19 bits, also starting
+    inside a byte), with the column at every offset modulo 16 in the arena: the
+    staged copy starts up to 15 bytes in front of the values and must not reach
+    the tile's bitmap words behind the stage."""
+    rng = np.random.default_rng(37)
+    cols = []
+    for dt, npt, per_tile, full in ((W.INT32, np.int32, 4096, 608), (W.INT64, np.int64, 2048, 304)):
+        mask = _mask_with_counts(rng, per_tile, [full, full, 5, 0, full, 1, 0, 0])
+        vals = rng.integers(1, 1 << 30, int(mask.sum())).astype(npt)
+        cols.append(E.encode_nullable(E.Nullable(data=E.Trivial(), nulls=E.Trivial()), vals, mask, dt))
+    for counts in ([1024, 0, 1024, 0, 0, 0, 0, 0], [3, 1024, 0, 0, 1, 1024, 0, 0, 0]):
+        mask = _mask_with_counts(rng, 4096, counts)
+        vals = rng.integers(0, 1 << 19, int(mask.sum())).astype(np.int32)
+        spec = E.Nullable(data=E.FixedBitWidth(bit_width=19, baseline=0), nulls=E.SparseBool())
+        cols.append(E.encode_nullable(spec, vals, mask, W.INT32))
+    for c in cols:
+        assert _uses_wave(c)
+    encs, labels, pos = [], [], 0
+    for r in range(16):
+        for i, c in enumerate(cols):
+            pad_rows = (r - pos - 7) % 16  # a Trivial<int8> of k rows is 7 + k bytes
+            encs.append(E.encode(E.Trivial(), np.arange(pad_rows, dtype=np.int8), W.INT8))
+            labels.append(f"pad before column {i} at offset {r} mod 16")
+            pos += len(encs[-1])
+            assert pos % 16 == r
+            encs.append(c)
+            labels.append(f"column {i} at offset {r} mod 16")
+            pos += len(c)
+    check_parity(oracle, encs, labels=labels)
