@@ -40,11 +40,8 @@ struct ColRef {
 enum KernelId : uint32_t {
   K_MATERIALIZE = 0,   // root leaf -> out               (src = c0)
   K_BITS_TO_BYTES,     // bool bitmap -> one byte per row (src = c0)
-  K_REDUCE_SUM,        // tile sums of a uint32 column    (src = c0)
-  K_REDUCE_POPC,       // tile popcounts of a bitmap      (src = sel, invert flag)
-  K_REDUCE_VARINT,     // tile counts of varint terminator bytes
-  K_SCAN_TILES,        // per node exclusive scan of its tile partials
-  K_RLE_ENDS,          // inclusive run ends
+  K_REDUCE_POPC,       // scanned rank partials of a bitmap (src = sel, invert flag): a chained scan
+  K_RLE_ENDS,          // inclusive run ends: a chained scan
   K_RLE_EXPAND,        // runs -> rows
   K_RLE_EXPAND_BOOL,   // bool runs -> bitmap
   K_SPARSE_BITS,       // sorted positions -> bitmap
@@ -99,18 +96,12 @@ enum NodeFlags : uint32_t {
                                // isCommon bitmap (other values where the bit is 0), c1 = its other values, aux3 = its
                                // common value, part_base2 / total_idx2 = its scanned rank partials and total
   NF_EMIT_PARTS = 1u << 8,   // K_SPARSE_BITS: the bitmap is the selection of its parent; also write the parent's rank
-                             // partials (part_base, aux2 = rows per parent tile; NF_INVERT_SEL: count the zero bits)
+                             // partials, already scanned, and its total (part_base / n_parts / total_idx are the
+                             // parent's, aux2 = rows per parent tile; NF_INVERT_SEL: count the zero bits)
   NF_SPARSE_DENSE = 1u << 9, // K_SPARSE_BITS: tiles of kBitTileRows rows instead of kSparseTileRows
   NF_BOOL_BYTES = 1u << 10,  // K_RLE_EXPAND_BOOL: the node is a chunk's root: self = its values in out, one byte per row
-  NF_WHOLE_NODE = 1u << 11,  // K_SPARSE_BITS / K_REDUCE_POPC: one workgroup holds the whole node (<= kWholeTileRows rows).
-                             // When it emits rank partials (NF_EMIT_PARTS, or always for K_REDUCE_POPC) it writes them
-                             // already scanned, with the node's totals (n_parts / total_idx are the parent's), so the
-                             // parent needs no scan step: one launch level less for columns of up to 131072 rows
-  NF_SELF_SCAN = 1u << 12,   // K_REDUCE_SUM / K_RLE_ENDS / K_STRING_VIEWS / K_VARINT_DECODE: no K_SCAN_TILES step runs for the node. Every
-                             // consumer tile adds up the tile sums in front of its own (parts[] stays as K_REDUCE_SUM
-                             // wrote it), its last tile writes the node's total, and the node's flag word is cleared by
-                             // K_REDUCE_SUM's first tile -- or, for a node of one tile, which has no K_REDUCE_SUM step
-                             // either, written by that tile
+  NF_WHOLE_NODE = 1u << 11,  // K_SPARSE_BITS / K_REDUCE_POPC: one workgroup holds the whole node (<= kWholeTileRows rows):
+                             // no search for a tile's range of positions, no ticket and no look-back
   NF_FRAME_BITS = 1u << 4,   // K_FRAME_UNPACK: FOR (u64 bit offsets, no raw marker) instead of
                              // BlockBitPacking (u32 byte offsets, width 255 = raw block)
 };
@@ -123,6 +114,7 @@ enum StatusBits : uint32_t {
   ST_VARINT_COUNT = 1u << 3,       // fewer varints than rowCount
   ST_STRING_BYTES = 1u << 4,       // string lengths exceed the blob
   ST_FRAME_RANGE = 1u << 5,        // block / frame offset or bit width outside the packed payload
+  ST_SCAN_STALL = 1u << 6,         // a chained scan gave up waiting for a tile in front of it (never expected)
 };
 
 struct NodeDesc {
@@ -142,8 +134,8 @@ struct NodeDesc {
   uint32_t flags;     // NodeFlags
   uint32_t part_base; // first slot of this node in the tile-partials array
   uint32_t n_parts;   // number of scan tiles
-  uint32_t total_idx; // slot in the node-totals array
-  uint32_t pad;
+  uint32_t total_idx; // slot in the node-totals array: [total, flag word, ticket counter of the chained scan, spare]
+  uint32_t look_base; // first look-back word of the node's chained scan (KArgs::look), one per scan tile
   uint64_t aux3;       // NF_NESTED_SELECT: fill value of the inner selection (its common value)
   uint32_t part_base2; // NF_NESTED_SELECT: first slot of the inner node's rank partials
   uint32_t total_idx2; // NF_NESTED_SELECT: the inner node's slot in the node-totals array
@@ -166,7 +158,9 @@ struct KArgs {
   uint32_t* parts;         // tile partials (work)
   uint32_t* totals;        // per-node totals (work)
   uint32_t* status;        // status word (work)
+  uint64_t* look;          // look-back words of the chained scans (work)
   uint32_t n_tiles;
+  uint32_t gen;            // number of this decode (1 .. 2^30 - 1): look-back words of any other number are stale
 };
 
 // Tile geometry: every row-producing kernel writes 16 KiB of output per
@@ -182,7 +176,6 @@ constexpr uint32_t kSparseTileWords = 1024;  // words per tile of the positions 
 constexpr uint32_t kSparseTileRows = kSparseTileWords * 64;
 constexpr uint32_t kWholeTileWords = 2048;   // words of a bitmap that one workgroup builds or counts alone (NF_WHOLE_NODE)
 constexpr uint32_t kWholeTileRows = kWholeTileWords * 64;
-constexpr uint32_t kSelfScanMaxTiles = 1024;  // NF_SELF_SCAN: at most this many tile sums per node (2M lengths)
 constexpr uint32_t kVarintTile = 4096;      // encoded bytes per varint tile
 // Rows per tile of the rank-scatter (Nullable / MainlyConstant) of `es`-byte elements.
 constexpr uint32_t select_tile_rows(uint32_t es) { return kTileBytes / es; }

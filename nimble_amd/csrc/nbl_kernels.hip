@@ -810,36 +810,99 @@ __device__ __forceinline__ void tile_words_to_bytes(const uint64_t* s_words, uin
   }
 }
 
-// -------------------------------------------------------------- tile reduces
-__device__ __forceinline__ void body_reduce_sum(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
-  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem);
-  const uint64_t n = nd.c0.rows;
-  const uint64_t t0 = (uint64_t)tile * kScanTile;            // < n: the tile exists
-  const uint32_t tn = n - t0 < kScanTile ? (uint32_t)(n - t0) : kScanTile;
-  const uint32_t r0 = threadIdx.x * 8;
-  uint32_t s = 0;
-  with_reader<4>(nd.c0, a, [&](auto rd) {
-    const auto src = rd.view(t0);
-    uint32_t v[8];
-#pragma unroll
-    for (uint32_t j = 0; j < 8; ++j) v[j] = src.at(r0 + j < tn ? r0 + j : tn - 1);
-#pragma unroll
-    for (uint32_t j = 0; j < 8; ++j) s += r0 + j < tn ? v[j] : 0u;
-  });
-  const uint32_t tot = block_sum(s, tmp);
+// ------------------------------------------------------------ chained scans
+// Data-dependent positions (run ends, string offsets, ranks of selected rows,
+// varint ordinals) need, per tile, the sum of everything in front of it.  A
+// node's tiles form a chain inside ONE launch: every tile publishes the sum of
+// its own elements as soon as it has it, then adds up the published sums of the
+// tiles in front of it, 64 at a time, back to the nearest tile that has already
+// published its inclusive prefix (a decoupled look-back), and publishes its own
+// inclusive prefix.  No tile waits for a tile that waits: aggregates do not
+// depend on anything, so the chain costs a few trips to memory whatever its
+// length, and no separate reduce / scan launch level exists.
+//
+// Tile order is the order in which a node's workgroups arrive (a ticket from an
+// atomic counter per node), not blockIdx: every tile in front of a waiting one
+// is then held by a workgroup that is already running, whatever order the
+// hardware dispatches workgroups in.  The tile holding the last ticket resets
+// the counter.  A look-back word is {value, number of the decode, flag bit,
+// prefix bit}: words left by an earlier decode do not match the number and read
+// as "not there yet", so nothing is cleared between decodes.  The wait is
+// bounded; giving up raises ST_SCAN_STALL.
+constexpr uint32_t kChainSpinLimit = 1u << 20;
+constexpr uint32_t kScratchOff = kStageBytes + 2048 + 1024;  // the 64 bytes of scratch every body may use
+__device__ __forceinline__ uint32_t* chain_lds(uint8_t* smem) { return reinterpret_cast<uint32_t*>(smem + kScratchOff) + 12; }
+__device__ __forceinline__ uint64_t look_pack(uint32_t value, uint32_t gen, uint32_t flag, uint32_t prefix) {
+  return ((uint64_t)((gen << 2) | (flag << 1) | prefix) << 32) | value;
+}
+__device__ __forceinline__ uint64_t look_ld(const uint64_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void look_st(uint64_t* p, uint64_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// The tile of the node this workgroup takes (0 for a node of one tile: no
+// counter is touched).  Every thread calls; the result is workgroup uniform.
+__device__ __forceinline__ uint32_t chain_ticket(const KArgs& a, const NodeDesc& nd, uint32_t n_tiles, uint8_t* smem) {
+  if (n_tiles <= 1) return 0u;
+  uint32_t* lds = chain_lds(smem);
+  uint32_t* counter = a.totals + nd.total_idx + 2;
   if (threadIdx.x == 0) {
-    a.parts[nd.part_base + tile] = tot;
-    if (tile == 0 && (nd.flags & NF_SELF_SCAN)) a.totals[nd.total_idx + 1] = 0;  // the node's flag word, as K_SCAN_TILES would
+    const uint32_t t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t + 1 >= n_tiles) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the last ticket: nobody asks again in this launch
+    lds[2] = t;
   }
+  __syncthreads();
+  const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds[2]);
+  return t < n_tiles ? t : n_tiles - 1;  // a counter that was not at zero (an aborted decode) stays in range
 }
 
-// NF_SELF_SCAN: the sum of the node's tile sums in front of tile `tile` (what
-// K_SCAN_TILES would have left in parts[tile]); at most kSelfScanMaxTiles of
-// them, written by an earlier launch.  Every thread calls.
-__device__ __forceinline__ uint32_t sum_of_tiles_before(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint32_t* tmp) {
-  uint32_t s = 0;
-  for (uint32_t i = threadIdx.x; i < tile; i += kBlock) s += a.parts[nd.part_base + i];
-  return block_sum(s, tmp);
+// Sum of the aggregates of tiles [0, t) of the node, flag_before = OR of their
+// flags; this tile's own (agg, flag) are published.  Every thread of the
+// 256-thread workgroup calls; the result is workgroup uniform.
+__device__ __forceinline__ uint32_t chain_exclusive(const KArgs& a, const NodeDesc& nd, uint32_t t, uint32_t n_tiles, uint32_t agg,
+                                                    uint32_t flag, uint32_t& flag_before, uint8_t* smem) {
+  flag_before = 0;
+  if (n_tiles <= 1) return 0u;
+  uint32_t* lds = chain_lds(smem);
+  if (threadIdx.x < 64) {
+    uint64_t* L = a.look + nd.look_base;
+    const uint32_t lane = threadIdx.x, gen = a.gen;
+    uint32_t excl = 0, fb = 0;
+    if (t == 0) {
+      if (lane == 0) look_st(L, look_pack(agg, gen, flag, 1u));
+    } else {
+      if (lane == 0) look_st(L + t, look_pack(agg, gen, flag, 0u));
+      int32_t hi = (int32_t)t - 1;  // the nearest tile in front whose word has not been added yet
+      uint32_t spins = 0;
+      while (hi >= 0) {
+        const int32_t i = hi - (int32_t)lane;
+        uint64_t w = 0;
+        if (i >= 0) w = look_ld(L + i);
+        const uint32_t h = (uint32_t)(w >> 32);
+        const bool there = i < 0 || (h >> 2) == gen;
+        const uint64_t missing = __ballot(!there);
+        const uint64_t prefixes = __ballot(i >= 0 && there && (h & 1u));
+        const uint32_t nr = missing ? (uint32_t)__ffsll((unsigned long long)missing) - 1u : 64u;    // words usable: lanes [0, nr)
+        const uint32_t np = prefixes ? (uint32_t)__ffsll((unsigned long long)prefixes) - 1u : 64u;  // nearest inclusive prefix
+        const uint32_t take = np < nr ? np + 1u : nr;
+        const bool mine = lane < take && i >= 0;
+        excl += wave_sum(mine ? (uint32_t)w : 0u);
+        fb |= __ballot(mine && (h & 2u)) != 0 ? 1u : 0u;
+        if (np < nr) break;
+        hi -= (int32_t)take;
+        if (nr < 64u) {
+          __builtin_amdgcn_s_sleep(2);
+          if (++spins > kChainSpinLimit) {
+            if (lane == 0) atomicOr(a.status, ST_SCAN_STALL);
+            break;
+          }
+        }
+      }
+      if (lane == 0) look_st(L + t, look_pack(excl + agg, gen, fb | flag, 1u));
+    }
+    if (lane == 0) { lds[0] = excl; lds[1] = fb; }
+  }
+  __syncthreads();
+  flag_before = lds[1];
+  return lds[0];
 }
 
 // Sum of `s` over the aligned group of `sub` consecutive threads (sub = 32, 64,
@@ -857,58 +920,55 @@ __device__ __forceinline__ uint32_t group_sum(uint32_t s, uint32_t sub, uint32_t
   return s;
 }
 
-// Rank partials of WPT * kBlock consecutive bitmap words, word
-// (tile * WPT + u) * kBlock + threadIdx.x counted in cnt[u]: one partial per
-// consumer tile of `sub` words (32, 64, 128 or 256) to parts[part_base + ..].
+// Rank partials of a tile of WPT * kBlock consecutive bitmap words (thread i
+// counted word u * kBlock + i of the tile in cnt[u]): one partial per consumer
+// tile of `sub` words (32, 64, 128 or 256), at most 64 of them.  Leaves the
+// exclusive prefix of every partial within the tile in s_part[0 .. 64) and
+// returns the tile's total.  s_part: 65 words; tmp: 4 words; every thread calls.
 template <uint32_t WPT>
-__device__ __forceinline__ void emit_rank_partials(const KArgs& a, uint32_t part_base, uint32_t sub, uint64_t rows, uint32_t tile,
-                                                   const uint32_t (&cnt)[WPT], uint32_t* tmp) {
+__device__ __forceinline__ uint32_t tile_partials_scan(uint32_t sub, const uint32_t (&cnt)[WPT], uint32_t* s_part, uint32_t* tmp) {
+  static_assert(WPT * kBlock <= kWholeTileWords, "at most 64 partials of at least 32 words");
+  __syncthreads();  // the caller's threads may still be reading what s_part held
 #pragma unroll
   for (uint32_t u = 0; u < WPT; ++u) {
-    const uint64_t w = ((uint64_t)tile * WPT + u) * kBitTileWords + threadIdx.x;
-    const bool live = w * 64 < rows;
     const uint32_t s = group_sum(cnt[u], sub, tmp);
-    if (live && (threadIdx.x & (sub - 1)) == 0) a.parts[part_base + (uint32_t)(w / sub)] = s;
-  }
-}
-
-// The same for a node that one workgroup holds alone (word u * kBlock +
-// threadIdx.x counted in cnt[u], zero past the node's rows): the partials are
-// written as the scan step would leave them -- exclusive prefixes, the total
-// behind the last one and in totals[total_idx], the node's flag word cleared --
-// so no scan step runs for the node.  n_parts <= 64 (a consumer tile has at
-// least 2048 rows, the node at most kWholeTileRows); lds: 4 + 64 words that
-// no thread still reads.
-template <uint32_t WPT>
-__device__ __forceinline__ void emit_scanned_partials(const KArgs& a, uint32_t part_base, uint32_t n_parts, uint32_t total_idx,
-                                                      uint32_t sub, const uint32_t (&cnt)[WPT], uint32_t* lds) {
-  static_assert(WPT * kBlock == kWholeTileWords, "one workgroup, the whole node");
-  uint32_t* s_part = lds + 4;
-  __syncthreads();  // the caller's threads may still be reading what lds held
-#pragma unroll
-  for (uint32_t u = 0; u < WPT; ++u) {
-    const uint32_t s = group_sum(cnt[u], sub, lds);
     const uint32_t slot = (u * kBlock + threadIdx.x) / sub;
     if ((threadIdx.x & (sub - 1)) == 0 && slot < 64) s_part[slot] = s;
   }
   __syncthreads();
   if (threadIdx.x < 64) {
-    const uint32_t np = n_parts < 64 ? n_parts : 64;
+    const uint32_t np = WPT * kBlock / sub;
     const uint32_t v = threadIdx.x < np ? s_part[threadIdx.x] : 0u;
     const uint32_t incl = wave_incl_scan(v);
-    if (threadIdx.x < np) a.parts[part_base + threadIdx.x] = incl - v;
-    if (threadIdx.x == 63) {
-      a.parts[part_base + np] = incl;
-      a.totals[total_idx] = incl;
-      a.totals[total_idx + 1] = 0;
-    }
+    s_part[threadIdx.x] = incl - v;
+    if (threadIdx.x == 63) s_part[64] = incl;
+  }
+  __syncthreads();
+  return s_part[64];
+}
+// Writes the partials tile_partials_scan() left, `before` added, as the scanned
+// rank partials of consumer tiles first_slot .. of a node of n_parts consumer
+// tiles; the node's last tile also writes the total behind the last partial and
+// into totals[total_idx], and clears the node's flag word.
+template <uint32_t WPT>
+__device__ __forceinline__ void write_scanned_partials(const KArgs& a, uint32_t part_base, uint32_t n_parts, uint32_t total_idx,
+                                                       uint32_t sub, uint32_t first_slot, uint32_t before, bool last_tile,
+                                                       const uint32_t* s_part) {
+  if (threadIdx.x < WPT * kBlock / sub && first_slot + threadIdx.x < n_parts) a.parts[part_base + first_slot + threadIdx.x] = before + s_part[threadIdx.x];
+  if (last_tile && threadIdx.x == 0) {
+    const uint32_t total = before + s_part[64];
+    a.parts[part_base + n_parts] = total;  // so that tile t's share is parts[t + 1] - parts[t] for every t
+    a.totals[total_idx] = total;
+    a.totals[total_idx + 1] = 0;
   }
 }
 
-// Set bits of the selection bitmap per consumer tile.  One workgroup counts
-// kPopcTileRows rows (kPopcWordsPerThread 64-bit words per thread, all loaded
-// before the first is counted) and emits one partial per consumer tile of
-// nd.aux2 rows.
+// K_REDUCE_POPC: scanned rank partials of a selection bitmap that no step of
+// this batch builds (a Trivial<bool> payload, or a bitmap another encoding
+// left in work).  One workgroup counts kPopcTileRows rows (kPopcWordsPerThread
+// 64-bit words per thread, all loaded before the first is counted), one partial
+// per consumer tile of nd.aux2 rows; the tiles of a node are a chained scan.  A
+// node of up to kWholeTileRows rows is one tile (NF_WHOLE_NODE).
 template <uint32_t WPT>
 __device__ __forceinline__ void reduce_popc_words(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint32_t (&cnt)[WPT]) {
   const BitsReader sel(nd.sel, a, (nd.flags & NF_INVERT_SEL) != 0);
@@ -921,70 +981,27 @@ __device__ __forceinline__ void reduce_popc_words(const KArgs& a, const NodeDesc
 #pragma unroll
   for (uint32_t u = 0; u < WPT; ++u) cnt[u] = (uint32_t)__popcll(wd[u]);
 }
-__device__ __forceinline__ void body_reduce_popc(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
-  if (nd.flags & NF_WHOLE_NODE) {  // the planner's choice for nodes of up to kWholeTileRows rows: counted and scanned here
+__device__ __forceinline__ void body_reduce_popc(const KArgs& a, const NodeDesc& nd, uint32_t, uint8_t* smem) {
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + kScratchOff);
+  uint32_t* s_part = reinterpret_cast<uint32_t*>(smem);
+  const uint32_t sub = (uint32_t)(nd.aux2 >> 6);
+  if (nd.flags & NF_WHOLE_NODE) {
     constexpr uint32_t WPT = kWholeTileWords / kBlock;
     uint32_t cnt[WPT];
     reduce_popc_words<WPT>(a, nd, 0, cnt);
-    emit_scanned_partials<WPT>(a, nd.part_base, nd.n_parts, nd.total_idx, (uint32_t)(nd.aux2 >> 6), cnt, reinterpret_cast<uint32_t*>(smem));
+    tile_partials_scan<WPT>(sub, cnt, s_part, tmp);
+    write_scanned_partials<WPT>(a, nd.part_base, nd.n_parts, nd.total_idx, sub, 0u, 0u, true, s_part);
     return;
   }
-  uint32_t cnt[kPopcWordsPerThread];
-  reduce_popc_words<kPopcWordsPerThread>(a, nd, tile, cnt);
-  emit_rank_partials<kPopcWordsPerThread>(a, nd.part_base, (uint32_t)(nd.aux2 >> 6), nd.sel.rows, tile, cnt, reinterpret_cast<uint32_t*>(smem));
-}
-
-// A varint starts at payload byte b when b == 0 or byte b-1 has its high bit
-// clear (common/Varint.h:78-81).  Tile = kVarintTile payload bytes.
-// Number of varints that start in the tile = number of bytes in
-// [t0 - 1, t0 + tile_len - 1) whose high bit is clear (the byte before the
-// payload counts as clear).  That range is read with aligned 16-byte loads.
-__device__ __forceinline__ void body_reduce_varint(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
-  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem);
-  const uint8_t* payload = a.arena + nd.c0.off;
-  const uint64_t len = nd.aux2;
-  const uint64_t t0 = (uint64_t)tile * kVarintTile;
-  const uint32_t tile_len = len - t0 < kVarintTile ? (uint32_t)(len - t0) : kVarintTile;
-  const uint8_t* first = payload + t0 - 1;                       // inside the arena: an encoding prefix precedes every payload
-  const uint32_t s0 = (uint32_t)(reinterpret_cast<uintptr_t>(first) & 15u);
-  const u32x4* base = reinterpret_cast<const u32x4*>(first - s0);
-  const uint32_t lo = s0 + (tile == 0 ? 1u : 0u), hi = s0 + tile_len;  // counted bytes: [lo, hi) relative to base
-  uint32_t cnt = 0;
-  for (uint32_t i = threadIdx.x; i * 16 < hi; i += kBlock) {
-    const u32x4 v = base[i];
-    auto clear_bits = [](uint32_t d) { const uint32_t t = ~d & 0x80808080u; return ((t >> 7) | (t >> 14) | (t >> 21) | (t >> 28)) & 0xFu; };
-    uint32_t c = clear_bits(v.x) | (clear_bits(v.y) << 4) | (clear_bits(v.z) << 8) | (clear_bits(v.w) << 12);
-    const uint32_t b0 = i * 16;
-    if (b0 < lo) c &= ~((1u << (lo - b0 > 16 ? 16 : lo - b0)) - 1u);
-    if (b0 + 16 > hi) c &= (1u << (hi - b0)) - 1u;
-    cnt += (uint32_t)__popc(c);
-  }
-  if (tile == 0 && threadIdx.x == 0 && tile_len) cnt += 1;      // the first byte of the payload always starts a value
-  const uint32_t tot = block_sum(cnt, tmp);
-  if (threadIdx.x == 0) a.parts[nd.part_base + tile] = tot;
-}
-
-// -------------------------------------------------------------- K_SCAN_TILES
-// One workgroup per node: exclusive scan of the node's tile partials in place,
-// grand total to totals[total_idx].
-__device__ __forceinline__ void body_scan_tiles(const KArgs& a, const NodeDesc& nd, uint32_t, uint8_t* smem) {
-  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem);
-  uint32_t* p = a.parts + nd.part_base;
-  const uint32_t n = nd.n_parts;
-  uint32_t carry = 0;
-  for (uint32_t base = 0; base < n; base += kBlock) {
-    const uint32_t i = base + threadIdx.x;
-    const uint32_t v = i < n ? p[i] : 0;
-    uint32_t total;
-    const uint32_t ex = block_excl_scan(v, tmp, total);
-    if (i < n) p[i] = carry + ex;
-    carry += total;
-  }
-  if (threadIdx.x == 0) {
-    a.totals[nd.total_idx] = carry;
-    a.totals[nd.total_idx + 1] = 0;  // the node's flag word (zero-length runs): set again by the steps after this one
-    p[n] = carry;  // so that tile t's share is p[t + 1] - p[t] for every t
-  }
+  constexpr uint32_t WPT = kPopcWordsPerThread;
+  const uint32_t n_tiles = (uint32_t)(((uint64_t)nd.sel.rows + kPopcTileRows - 1) / kPopcTileRows);
+  const uint32_t tile = chain_ticket(a, nd, n_tiles, smem);
+  uint32_t cnt[WPT];
+  reduce_popc_words<WPT>(a, nd, tile, cnt);
+  const uint32_t total = tile_partials_scan<WPT>(sub, cnt, s_part, tmp);
+  uint32_t unused;
+  const uint32_t before = chain_exclusive(a, nd, tile, n_tiles, total, 0u, unused, smem);
+  write_scanned_partials<WPT>(a, nd.part_base, nd.n_parts, nd.total_idx, sub, tile * (WPT * kBlock / sub), before, tile + 1 == n_tiles, s_part);
 }
 
 // first_run[] of an RLE node sits behind its run-end array (R entries, 16-byte rounded)
@@ -993,10 +1010,14 @@ __device__ __forceinline__ uint32_t* rle_first_run(const KArgs& a, const NodeDes
 }
 
 // ---------------------------------------------------------------- K_RLE_ENDS
-// ends[k] = len[0] + ... + len[k]; flags zero-length runs in totals[total_idx+1].
-__device__ __forceinline__ void body_rle_ends(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
-  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem);
+// ends[k] = len[0] + ... + len[k] (a chained scan over the node's tiles of
+// kScanTile runs); the node's last tile leaves the sum of all lengths in
+// totals[total_idx] and "some run has length zero" in totals[total_idx + 1].
+__device__ __forceinline__ void body_rle_ends(const KArgs& a, const NodeDesc& nd, uint32_t, uint8_t* smem) {
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + kScratchOff);
   const uint64_t n = nd.c0.rows;
+  const uint32_t n_tiles = nd.n_parts;
+  const uint32_t tile = chain_ticket(a, nd, n_tiles, smem);
   const uint64_t e0 = (uint64_t)tile * kScanTile + (uint64_t)threadIdx.x * 8;
   uint32_t v[8];
   uint32_t s = 0;
@@ -1018,11 +1039,16 @@ __device__ __forceinline__ void body_rle_ends(const KArgs& a, const NodeDesc& nd
     s += len;
     v[j] = s;
   }
-  const bool self_scan = (nd.flags & NF_SELF_SCAN) != 0;
-  const uint32_t before = self_scan ? sum_of_tiles_before(a, nd, tile, tmp) : sload32(a.parts + nd.part_base + tile);
   uint32_t total;
-  const uint32_t ex = block_excl_scan(s, tmp, total) + before;
-  if (self_scan && tile + 1 == nd.n_parts && threadIdx.x == 0) a.totals[nd.total_idx] = before + total;
+  uint32_t ex = block_excl_scan(s, tmp, total);
+  const uint32_t any_zero = __syncthreads_or(zero) ? 1u : 0u;
+  uint32_t zero_before;
+  const uint32_t before = chain_exclusive(a, nd, tile, n_tiles, total, any_zero, zero_before, smem);
+  ex += before;
+  if (tile + 1 == n_tiles && threadIdx.x == 0) {
+    a.totals[nd.total_idx] = before + total;
+    a.totals[nd.total_idx + 1] = zero_before | any_zero;
+  }
   uint32_t* ends = reinterpret_cast<uint32_t*>(a.work + nd.aux_off);
   if (e0 + 8 <= n) {
     *reinterpret_cast<u32x4*>(ends + e0) = make_u32x4(v[0] + ex, v[1] + ex, v[2] + ex, v[3] + ex);
@@ -1031,12 +1057,6 @@ __device__ __forceinline__ void body_rle_ends(const KArgs& a, const NodeDesc& nd
 #pragma unroll
     for (uint32_t j = 0; j < 8; ++j)
       if (e0 + j < n) ends[e0 + j] = v[j] + ex;
-  }
-  if (self_scan && nd.n_parts == 1) {  // the node's only tile: it writes the flag word itself
-    const int any_zero = __syncthreads_or(zero);
-    if (threadIdx.x == 0) a.totals[nd.total_idx + 1] = any_zero ? 1u : 0u;
-  } else if (__ballot(zero) != 0 && lane_id() == 0) {
-    atomicOr(&a.totals[nd.total_idx + 1], 1u);
   }
   // first_run[t] = the run that holds row t * tile_rows, for every output tile t:
   // run i covers rows [start, end), so it is the first run of every tile whose
@@ -1383,10 +1403,26 @@ __device__ __forceinline__ void sparse_bits_tile(const KArgs& a, const NodeDesc&
       cnt[u] = (uint32_t)__popcll(zeros ? ~v & m : v);
     }
   }
-  if constexpr (W == kWholeTileWords) {
-    if (emit) emit_scanned_partials<WPT>(a, nd.part_base, nd.n_parts, nd.total_idx, (uint32_t)(nd.aux2 >> 6), cnt, reinterpret_cast<uint32_t*>(smem));
-  } else {
-    if (emit) emit_rank_partials<WPT>(a, nd.part_base, (uint32_t)(nd.aux2 >> 6), rows, tile, cnt, reinterpret_cast<uint32_t*>(smem));
+  if (emit) {
+    // The partials go out scanned, without a chain: the positions are sorted, so
+    // those in front of the tile's first one, `lo` of them, are exactly the
+    // listed rows in front of the tile.  The same property is checked for the
+    // tile itself -- its range of the list must have put that many distinct bits
+    // into it (the sentinel behind the last row aside) -- so a list that is not
+    // sorted raises the status bit instead of yielding ranks that do not add up.
+    const uint32_t lo = s_k[0], hi = s_k[1];
+    uint32_t* tmp = reinterpret_cast<uint32_t*>(smem);
+    uint32_t* s_part = tmp + 4;
+    const uint32_t sub = (uint32_t)(nd.aux2 >> 6);
+    const uint32_t total = tile_partials_scan<WPT>(sub, cnt, s_part, tmp);
+    const bool listed_selected = ((nd.flags & NF_SPARSE_VALUE) != 0) != zeros;  // the parent selects the listed rows
+    const uint32_t before = listed_selected ? lo : (uint32_t)p0 - lo;
+    const bool last = p1 == rows;
+    write_scanned_partials<WPT>(a, nd.part_base, nd.n_parts, nd.total_idx, sub, tile * (W / sub), before, last, s_part);
+    const uint32_t listed_here = listed_selected ? total : (uint32_t)(p1 - p0) - total;
+    const uint32_t in_range = hi > lo ? hi - lo : 0u;
+    const bool bad = lo > (uint32_t)p0 || (last ? (in_range == 0 || listed_here != in_range - 1) : listed_here != in_range);
+    if (bad && threadIdx.x == 0) atomicOr(a.status, ST_SELECT_COUNT);
   }
 #pragma unroll
   for (uint32_t u = 0; u < WPT; ++u) {
@@ -2342,8 +2378,10 @@ __device__ __forceinline__ void body_dict_gather(const KArgs& a, const NodeDesc&
 // i of the tile from LDS, so the work is balanced whatever the lengths are and
 // the stores of a wave are consecutive.
 template <int ES>
-__device__ __forceinline__ void body_varint_decode(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
+__device__ __forceinline__ void body_varint_decode(const KArgs& a, const NodeDesc& nd, uint32_t, uint8_t* smem) {
   using T = typename ElemT<ES>::type;
+  const uint32_t n_tiles = nd.n_parts;
+  const uint32_t tile = chain_ticket(a, nd, n_tiles, smem);
   u32x4* stage = reinterpret_cast<u32x4*>(smem);                        // <= 16 + 4096 + 10 + 15 + 4 bytes
   uint16_t* s_start = reinterpret_cast<uint16_t*>(smem + 8192);          // <= 4096 offsets
   uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + kStageBytes + 3072);
@@ -2381,13 +2419,11 @@ __device__ __forceinline__ void body_varint_decode(const KArgs& a, const NodeDes
   }
   __syncthreads();
   // pass 2
-  const bool self_scan = (nd.flags & NF_SELF_SCAN) != 0;
-  const uint64_t rank0 = self_scan ? sum_of_tiles_before(a, nd, tile, tmp) : sload32(a.parts + nd.part_base + tile);
-  if (self_scan) {  // the last tile knows how many values the payload holds
-    if (tile + 1 == nd.n_parts && threadIdx.x == 0 && rank0 + count < rows) atomicOr(a.status, ST_VARINT_COUNT);
-  } else if (tile == 0 && threadIdx.x == 0 && sload32(a.totals + nd.total_idx) < nd.rows) {
-    atomicOr(a.status, ST_VARINT_COUNT);
-  }
+  // the ordinal of the tile's first value: a chained scan of the tiles' counts
+  uint32_t unused;
+  const uint64_t rank0 = chain_exclusive(a, nd, tile, n_tiles, count, 0u, unused, smem);
+  // the last tile knows how many values the payload holds
+  if (tile + 1 == n_tiles && threadIdx.x == 0 && rank0 + count < rows) atomicOr(a.status, ST_VARINT_COUNT);
   for (uint32_t i = threadIdx.x; i < count; i += kBlock) {
     if (rank0 + i >= rows) break;
     const uint32_t off = s_start[i];
@@ -2421,9 +2457,11 @@ __device__ __forceinline__ void body_varint_decode(const KArgs& a, const NodeDes
 // TrivialEncoding<string_view>::materialize (encodings/TrivialEncoding.cpp:151-164):
 // view i = {running sum of lengths, length i}; emitted as uint64 = len << 32 | offset,
 // offset relative to the chunk's string region.
-__device__ __forceinline__ void body_string_views(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
-  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem);
+__device__ __forceinline__ void body_string_views(const KArgs& a, const NodeDesc& nd, uint32_t, uint8_t* smem) {
+  uint32_t* tmp = reinterpret_cast<uint32_t*>(smem + kScratchOff);
   const uint64_t n = nd.rows;
+  const uint32_t n_tiles = nd.n_parts;
+  const uint32_t tile = chain_ticket(a, nd, n_tiles, smem);  // the offsets are a chained scan over the node's tiles
   const uint64_t e0 = (uint64_t)tile * kScanTile + (uint64_t)threadIdx.x * 8;
   uint32_t len[8];
   uint32_t s = 0;
@@ -2442,10 +2480,11 @@ __device__ __forceinline__ void body_string_views(const KArgs& a, const NodeDesc
     len[j] = e0 + j < n ? len[j] : 0;
     s += len[j];
   }
-  const bool self_scan = (nd.flags & NF_SELF_SCAN) != 0;
-  const uint32_t before = self_scan ? sum_of_tiles_before(a, nd, tile, tmp) : sload32(a.parts + nd.part_base + tile);
   uint32_t total;
-  uint32_t off = block_excl_scan(s, tmp, total) + before + (uint32_t)nd.aux;
+  uint32_t off = block_excl_scan(s, tmp, total);
+  uint32_t unused;
+  const uint32_t before = chain_exclusive(a, nd, tile, n_tiles, total, 0u, unused, smem);
+  off += before + (uint32_t)nd.aux;
   uint64_t* dst = reinterpret_cast<uint64_t*>(self_ptr(nd, a));
   uint64_t v[8];
 #pragma unroll
@@ -2462,11 +2501,8 @@ __device__ __forceinline__ void body_string_views(const KArgs& a, const NodeDesc
     for (uint32_t j = 0; j < 8; ++j)
       if (e0 + j < n) dst[e0 + j] = v[j];
   }
-  if (self_scan) {  // the last tile knows the sum of all lengths
-    if (tile + 1 == nd.n_parts && threadIdx.x == 0 && (uint64_t)before + total > nd.aux2) atomicOr(a.status, ST_STRING_BYTES);
-  } else if (tile == 0 && threadIdx.x == 0 && sload32(a.totals + nd.total_idx) > nd.aux2) {
-    atomicOr(a.status, ST_STRING_BYTES);
-  }
+  // the last tile knows the sum of all lengths
+  if (tile + 1 == n_tiles && threadIdx.x == 0 && (uint64_t)before + total > nd.aux2) atomicOr(a.status, ST_STRING_BYTES);
 }
 
 // -------------------------------------------------------------- K_COPY_BYTES
@@ -2710,10 +2746,7 @@ __device__ __forceinline__ void run_op(const KArgs& a, const NodeDesc& nd, uint3
   else if constexpr (K == K_MATERIALIZE_FBW) body_materialize_fbw<ES>(a, nd, tile, smem);
   else if constexpr (K == K_MATERIALIZE_RAW) body_materialize_raw<ES>(a, nd, tile, smem);
   else if constexpr (K == K_BITS_TO_BYTES) body_bits_to_bytes(a, nd, tile, smem);
-  else if constexpr (K == K_REDUCE_SUM) body_reduce_sum(a, nd, tile, smem);
   else if constexpr (K == K_REDUCE_POPC) body_reduce_popc(a, nd, tile, smem);
-  else if constexpr (K == K_REDUCE_VARINT) body_reduce_varint(a, nd, tile, smem);
-  else if constexpr (K == K_SCAN_TILES) body_scan_tiles(a, nd, tile, smem);
   else if constexpr (K == K_RLE_ENDS) body_rle_ends(a, nd, tile, smem);
   else if constexpr (K == K_RLE_EXPAND) body_rle_expand<ES>(a, nd, tile, smem);
   else if constexpr (K == K_RLE_EXPAND_BOOL) body_rle_expand_bool(a, nd, tile, smem);
@@ -2767,10 +2800,7 @@ NBL_KERNEL_ES(k_materialize, K_MATERIALIZE)
 NBL_KERNEL_ES(k_materialize_fbw, K_MATERIALIZE_FBW)
 NBL_KERNEL_ES(k_materialize_raw, K_MATERIALIZE_RAW)
 NBL_KERNEL(k_bits_to_bytes, K_BITS_TO_BYTES)
-NBL_KERNEL(k_reduce_sum, K_REDUCE_SUM)
 NBL_KERNEL(k_reduce_popc, K_REDUCE_POPC)
-NBL_KERNEL(k_reduce_varint, K_REDUCE_VARINT)
-NBL_KERNEL(k_scan_tiles, K_SCAN_TILES)
 NBL_KERNEL(k_rle_ends, K_RLE_ENDS)
 NBL_KERNEL_ES(k_rle_expand, K_RLE_EXPAND)
 NBL_KERNEL(k_rle_expand_bool, K_RLE_EXPAND_BOOL)
@@ -2810,7 +2840,8 @@ typedef const KArgs __attribute__((address_space(4))) * KArgsSegment;
 __device__ __forceinline__ KArgs load_args(KArgsSegment k) {
   KArgs a;
   a.arena = k->arena; a.out = k->out; a.work = k->work; a.nodes = k->nodes; a.tiles = k->tiles;
-  a.tile_aux = k->tile_aux; a.parts = k->parts; a.totals = k->totals; a.status = k->status; a.n_tiles = k->n_tiles;
+  a.tile_aux = k->tile_aux; a.parts = k->parts; a.totals = k->totals; a.status = k->status; a.look = k->look;
+  a.n_tiles = k->n_tiles; a.gen = k->gen;
   return a;
 }
 
@@ -2837,10 +2868,7 @@ __global__ __launch_bounds__(256, 8) void k_level(KArgs) {
     NBL_OP_ALL_ES(K_MATERIALIZE_FBW)
     NBL_OP_ALL_ES(K_MATERIALIZE_RAW)
     NBL_OP(K_BITS_TO_BYTES, 1)
-    NBL_OP(K_REDUCE_SUM, 1)
     NBL_OP(K_REDUCE_POPC, 1)
-    NBL_OP(K_REDUCE_VARINT, 1)
-    NBL_OP(K_SCAN_TILES, 1)
     NBL_OP(K_RLE_ENDS, 1)
     NBL_OP_ALL_ES(K_RLE_EXPAND)
     NBL_OP(K_RLE_EXPAND_BOOL, 1)
@@ -2892,10 +2920,7 @@ extern "C" int nbl_launch_kernel(uint32_t kernel, uint32_t es, const nbl::KArgs*
     case K_MATERIALIZE_FBW: NBL_BY_ES(k_materialize_fbw); break;
     case K_MATERIALIZE_RAW: NBL_BY_ES(k_materialize_raw); break;
     case K_BITS_TO_BYTES: hipLaunchKernelGGL(k_bits_to_bytes, grid, block, 0, s, a); break;
-    case K_REDUCE_SUM: hipLaunchKernelGGL(k_reduce_sum, grid, block, 0, s, a); break;
     case K_REDUCE_POPC: hipLaunchKernelGGL(k_reduce_popc, grid, block, 0, s, a); break;
-    case K_REDUCE_VARINT: hipLaunchKernelGGL(k_reduce_varint, grid, block, 0, s, a); break;
-    case K_SCAN_TILES: hipLaunchKernelGGL(k_scan_tiles, grid, block, 0, s, a); break;
     case K_RLE_ENDS: hipLaunchKernelGGL(k_rle_ends, grid, block, 0, s, a); break;
     case K_RLE_EXPAND: NBL_BY_ES(k_rle_expand); break;
     case K_RLE_EXPAND_BOOL: hipLaunchKernelGGL(k_rle_expand_bool, grid, block, 0, s, a); break;

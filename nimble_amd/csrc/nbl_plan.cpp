@@ -10,6 +10,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -123,7 +124,6 @@ struct Step {
   uint32_t es;
   uint32_t dnode;
   uint32_t n_tiles;
-  bool per_node;  // K_SCAN_TILES: one workgroup, tile index unused
   int chunk;      // >= 0 when this step writes the final values of that chunk
   int owner;      // chunk the step belongs to
   uint32_t tile_begin = 0;  // first tile of the node this step covers (steps can be split)
@@ -140,8 +140,7 @@ struct Launch {
 };
 
 const char* kKernelNames[K_COUNT] = {
-    "k_materialize", "k_bits_to_bytes", "k_reduce_sum", "k_reduce_popc", "k_reduce_varint",
-    "k_scan_tiles", "k_rle_ends", "k_rle_expand", "k_rle_expand_bool", "k_sparse_bits",
+    "k_materialize", "k_bits_to_bytes", "k_reduce_popc", "k_rle_ends", "k_rle_expand", "k_rle_expand_bool", "k_sparse_bits",
     "k_select_scatter", "k_dict_gather", "k_varint_decode", "k_string_views", "k_copy_bytes",
     "k_select_bits", "k_materialize_fbw", "k_materialize_raw", "k_frame_unpack", "k_select_scatter_wave"};
 
@@ -172,7 +171,9 @@ struct nbl_plan {
   uint64_t tiles_off = 0, aux_off = 0;
   uint64_t ctrl_off = 0, ctrl_bytes = 0;   // status word + per-node totals (zeroed by the upload)
   uint64_t parts_off = 0;
-  uint32_t n_parts = 0, n_totals = 0;
+  uint32_t n_parts = 0, n_totals = 0, n_look = 0;
+  uint64_t look_off = 0;
+  mutable std::atomic<uint32_t> decodes{0};  // number of the last decode (look-back words carry it)
   uint64_t out_bytes = 0, work_bytes = 0, desc_bytes = 0;
   uint64_t cur_out = 0, cur_work = 0;      // allocation cursors
   uint64_t cur_str = 0;                    // string bytes of the chunk being planned
@@ -195,14 +196,20 @@ struct nbl_plan {
     aux_in_work.push_back(aux_work ? 1 : 0);
     return (uint32_t)dnodes.size() - 1;
   }
-  void add_step(int level, uint32_t kernel, uint32_t es, uint32_t dnode, uint32_t n_tiles, bool per_node = false) {
+  void add_step(int level, uint32_t kernel, uint32_t es, uint32_t dnode, uint32_t n_tiles) {
     if (n_tiles == 0) return;
     if (n_tiles > kTileMask) fail(NBL_ERR_UNSUPPORTED, "a node of %u tiles exceeds the tile table's range", n_tiles);
-    steps.push_back(Step{level, kernel, es, dnode, n_tiles, per_node, -1, cur_chunk, 0, 0});
+    steps.push_back(Step{level, kernel, es, dnode, n_tiles, -1, cur_chunk, 0, 0});
   }
-  void alloc_scan(NodeDesc& d, uint32_t n_tiles) {
-    d.part_base = n_parts; d.n_parts = n_tiles; n_parts += n_tiles + 1;  // + the node's total behind its last partial
-    d.total_idx = n_totals; n_totals += 2;
+  // A node whose positions depend on its data: the totals slot (total, flag
+  // word, ticket counter, spare), `chain_tiles` look-back words for a chained
+  // scan over that many tiles, and -- for the rank scatters, whose tiles read
+  // their share from a table -- `rank_parts` scanned partials (+ the total).
+  void alloc_scan(NodeDesc& d, uint32_t n_tiles, uint32_t chain_tiles, bool rank_parts) {
+    d.n_parts = n_tiles;
+    if (rank_parts) { d.part_base = n_parts; n_parts += n_tiles + 1; }
+    d.total_idx = n_totals; n_totals += 4;
+    d.look_base = n_look; n_look += chain_tiles > 1 ? chain_tiles : 0;
   }
   uint64_t string_copy(int level, uint64_t arena_off, uint64_t bytes);
   uint64_t column_to_out(const ColRef& src, uint32_t rows, uint32_t es, int level);
@@ -615,18 +622,10 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
         d.c0 = C(0).ref; d.c0.rows = std::min(d.c0.rows, C(0).rows);
         d.rows = rows; d.aux = rel; d.aux2 = nn.payload_bytes;
         const uint32_t nt = div_up32(rows, kScanTile);
-        alloc_scan(d, nt);
-        // up to kSelfScanMaxTiles tile sums: the view tiles add up the sums in front
-        // of their own instead of a scan step doing it (one launch level less); a
-        // column of one tile needs no sums at all
-        const bool self_scan = nt <= kSelfScanMaxTiles;
-        if (self_scan) d.flags |= NF_SELF_SCAN;
+        alloc_scan(d, nt, nt, false);  // the offsets: a chained scan over the view tiles, one step
         const uint32_t dn = add_dnode(d);
-        int at = lvl;
-        if (nt > 1 || !self_scan) add_step(at++, K_REDUCE_SUM, 4, dn, nt);
-        if (!self_scan) add_step(at++, K_SCAN_TILES, 0, dn, 1, true);
-        add_step(at++, K_STRING_VIEWS, 8, dn, nt);
-        nn.ref = d.self; nn.ready = at;
+        add_step(lvl, K_STRING_VIEWS, 8, dn, nt);
+        nn.ref = d.self; nn.ready = lvl + 1;
       } else if (nn.is_bool) {
         ColRef r{}; r.kind = COL_BITS_RAW; r.off = nn.payload_off; r.rows = rows;
         nn.ref = r; nn.ready = 0;
@@ -653,17 +652,10 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       d.c0.kind = COL_RAW; d.c0.off = nn.payload_off; d.c0.base = nn.value; d.c0.rows = rows; d.c0.es = (uint8_t)es;
       d.rows = rows; d.aux2 = nn.payload_bytes;
       const uint32_t nt = div_up32(nn.payload_bytes, kVarintTile);
-      alloc_scan(d, nt);
-      // (as for run ends and string views: the decode tiles add up the tile
-      // counts in front of their own, a payload of one tile needs no counts)
-      const bool self_scan = nt <= kSelfScanMaxTiles;
-      if (self_scan) d.flags |= NF_SELF_SCAN;
+      alloc_scan(d, nt, nt, false);  // the ordinals: a chained scan over the decode tiles, one step
       const uint32_t dn = add_dnode(d);
-      int at = lvl;
-      if (nt > 1 || !self_scan) add_step(at++, K_REDUCE_VARINT, 0, dn, nt);
-      if (!self_scan) add_step(at++, K_SCAN_TILES, 0, dn, 1, true);
-      add_step(at++, K_VARINT_DECODE, es, dn, nt);
-      nn.ref = d.self; nn.ready = at;
+      add_step(lvl, K_VARINT_DECODE, es, dn, nt);
+      nn.ref = d.self; nn.ready = lvl + 1;
       break;
     }
     case ET_RLE: {
@@ -685,7 +677,7 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       const uint32_t R = C(0).rows;
       d.c0.rows = R;
       const uint32_t nt = div_up32(R, kScanTile);
-      alloc_scan(d, nt);
+      alloc_scan(d, nt, nt, false);  // the run ends: a chained scan over the tiles of runs, one step
       // run ends (R entries, 16-byte rounded) followed by first_run[] (one entry per output tile)
       const uint32_t out_tile_rows = nn.is_bool ? kBitTileRows : tile_rows;
       d.aux2 = out_tile_rows;
@@ -702,15 +694,8 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
         if (!nn.fused_runs) d.self = mat_ref(es);
         d.c1 = C(1).ref;
       }
-      // up to kSelfScanMaxTiles tile sums: the run-end tiles add up the sums in
-      // front of their own instead of a scan step doing it (one launch level less);
-      // a column of one tile of runs needs no sums at all
-      const bool self_scan = nt <= kSelfScanMaxTiles;
-      if (self_scan) d.flags |= NF_SELF_SCAN;
       const uint32_t dn = add_dnode(d, /*aux_work=*/true);
       int at = lvl;
-      if (nt > 1 || !self_scan) add_step(at++, K_REDUCE_SUM, 4, dn, nt);
-      if (!self_scan) add_step(at++, K_SCAN_TILES, 0, dn, 1, true);
       add_step(at++, K_RLE_ENDS, 4, dn, nt);
       if (nn.fused_runs) {
         // the parent expands: hand it the run ends (a work array, rebased with the
@@ -830,37 +815,32 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       const uint32_t trows = nn.is_bool ? kBitTileRows : select_tile_rows(es);
       d.aux2 = trows;
       const uint32_t nt = div_up32(rows, trows);
-      alloc_scan(d, nt);
-      // the ranks need the selection bitmap only: counted and scanned as soon as
-      // that child is ready, underneath whatever the values child still has to do.
-      // A SparseBool selection counts them while it builds the bitmap.
+      // The ranks need the selection bitmap only, and they come scanned out of one
+      // step: a SparseBool selection writes them while it builds the bitmap (its
+      // sorted positions give every tile the count in front of it), any other
+      // bitmap is counted by a chained scan as soon as that child is ready,
+      // underneath whatever the values child still has to do.
       const PNode& selc = nullable ? C(1) : C(0);
       const bool counted = selc.enc == ET_SPARSEBOOL && selc.sparse_dn >= 0 && selc.rows == rows;
-      // a node that one workgroup counts alone leaves its partials scanned: no scan step
-      bool scanned = false;
+      const bool whole = !counted && rows > 0 && rows <= kWholeTileRows;  // one workgroup counts the node alone
+      const uint32_t popc_tiles = whole ? 1u : div_up32(rows, kPopcTileRows);
+      alloc_scan(d, nt, counted ? 0u : popc_tiles, true);
       if (counted) {
         NodeDesc& sd = dnodes[(size_t)selc.sparse_dn];
         sd.flags |= NF_EMIT_PARTS | (nullable ? 0u : (uint32_t)NF_INVERT_SEL);
         sd.part_base = d.part_base;
+        sd.n_parts = d.n_parts;
+        sd.total_idx = d.total_idx;
         sd.aux2 = trows;
-        if (sd.flags & NF_WHOLE_NODE) {
-          sd.n_parts = d.n_parts;
-          sd.total_idx = d.total_idx;
-          scanned = true;
-        }
-      } else if (rows > 0 && rows <= kWholeTileRows) {
+      } else if (whole) {
         d.flags |= NF_WHOLE_NODE;
-        scanned = true;
       }
       const int sel_lvl = selc.ready;
-      const int scan_lvl = counted ? sel_lvl : sel_lvl + 1;
-      const int fin = std::max(lvl, scanned ? scan_lvl : scan_lvl + 1);
-      const uint32_t popc_tiles = scanned ? 1u : div_up32(rows, kPopcTileRows);
+      const int fin = std::max(lvl, counted ? sel_lvl : sel_lvl + 1);
       if (nn.fused_select) {
-        // the parent scatters for this node: it only counts and scans its ranks
+        // the parent scatters for this node: it only counts its ranks
         const uint32_t dn = add_dnode(d);
         if (!counted) add_step(sel_lvl, K_REDUCE_POPC, 0, dn, popc_tiles);
-        if (!scanned) add_step(scan_lvl, K_SCAN_TILES, 0, dn, 1, true);
         nn.sel_ref = d.sel;
         nn.sel_part_base = d.part_base;
         nn.sel_total_idx = d.total_idx;
@@ -872,7 +852,6 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       d.self = nn.is_bool ? bits_ref() : mat_ref(es);
       const uint32_t dn = add_dnode(d);
       if (!counted) add_step(sel_lvl, K_REDUCE_POPC, 0, dn, popc_tiles);  // each tile emits the partials of kPopcTileRows / trows consumer tiles
-      if (!scanned) add_step(scan_lvl, K_SCAN_TILES, 0, dn, 1, true);
       // Tiles that stage few values (a sparse selection, or a nested one whose
       // staged values are the few "other" ones) go to the one-wave kernel: on the
       // column's average a tile may fill two thirds of that kernel's stage.
@@ -1196,7 +1175,8 @@ void nbl_plan::finish() {
   aux_off = nd_bytes + tl_bytes;
   desc_bytes = nd_bytes + tl_bytes + ax_bytes;
   ctrl_off = desc_bytes;
-  ctrl_bytes = align_up(4 + (uint64_t)n_totals * 4, kAlign);
+  look_off = align_up(4 + (uint64_t)n_totals * 4, 8);  // relative to ctrl_off
+  ctrl_bytes = align_up(look_off + (uint64_t)n_look * 8, kAlign);
   parts_off = ctrl_off + ctrl_bytes;
   const uint64_t scratch_base = align_up(parts_off + (uint64_t)n_parts * 4, kAlign);
   // intermediates were allocated from a cursor starting at 0: rebase them
@@ -1459,6 +1439,10 @@ static nbl_status decode_impl(const nbl_plan* p, nbl_profile* prof, uint32_t ste
   a.status = reinterpret_cast<uint32_t*>(work + p->ctrl_off);
   a.totals = a.status + 1;
   a.parts = reinterpret_cast<uint32_t*>(work + p->parts_off);
+  a.look = reinterpret_cast<uint64_t*>(work + p->ctrl_off + p->look_off);
+  // every decode has a number of its own (1 .. 2^30 - 1): the chained scans tell
+  // this decode's look-back words from those an earlier one left in `work`
+  a.gen = (p->decodes.fetch_add(1, std::memory_order_relaxed) % 0x3FFFFFFFu) + 1u;
   const TileRef* tiles = reinterpret_cast<const TileRef*>(work + p->tiles_off);
   const uint32_t* tile_aux = reinterpret_cast<const uint32_t*>(work + p->aux_off);
   const size_t nl = p->launches.size();
@@ -1505,6 +1489,7 @@ nbl_status nbl_decode_status(const nbl_plan* p, const void* d_work, void* stream
   if (st & ST_VARINT_COUNT) m += " fewer varints than rows;";
   if (st & ST_STRING_BYTES) m += " string lengths exceed the blob;";
   if (st & ST_FRAME_RANGE) m += " block offset or bit width outside the packed payload;";
+  if (st & ST_SCAN_STALL) m += " a chained scan gave up waiting;";
   g_last_error = m;
   return NBL_ERR_DEVICE_DATA;
 }

@@ -210,19 +210,19 @@ def test_leaf_only_chunks_fill_the_preparatory_levels():
     deep = [E.encode(E.RLE(), np.repeat(rng.integers(0, 50, n // 20), 20).astype(np.int64), W.INT64)]
     p = Plan.from_encodings(leaf + deep)
     launches = p.launches()
-    assert len(launches) == 3  # tile sums, run ends (each tile adds up the sums in front of its own), expand
+    assert len(launches) == 2  # run ends (a chained scan over the tiles of runs), expand
     tiles = [l[2] for l in launches]
     assert min(tiles) > 100 and max(tiles) < 3 * min(tiles), tiles
     only_deep = Plan.from_encodings(deep)
-    assert [l[2] for l in only_deep.launches()][:2] == [10, 10]  # 20,000 runs: ten tiles of sums, ten of run ends
+    assert [l[2] for l in only_deep.launches()][:1] == [10]  # 20,000 runs: ten tiles of run ends
     p.close(); only_deep.close()
 
 
 def test_rank_counting_is_placed_at_the_bitmap_level():
-    """The popcount partials and their scan of a Nullable read the null bitmap
-    only: under a deep values child (RLE: sums, scan, run ends) they run
-    alongside its first steps.  The rank scatter expands the runs itself, so the
-    RLE has no expand step and the scatter follows the run ends directly."""
+    """The rank partials of a Nullable read the null bitmap only: under a values
+    child that has steps of its own (RLE: run ends) they run alongside them.
+    Both are chained scans, one step each.  The rank scatter expands the runs
+    itself, so the RLE has no expand step and the scatter follows directly."""
     rng = np.random.default_rng(5)
     n = 300_000
     mask = rng.random(n) < 0.7
@@ -232,13 +232,12 @@ def test_rank_counting_is_placed_at_the_bitmap_level():
     level = {}
     for name, _, _, lvl, _ in p.launches():
         level.setdefault(name, lvl)
-    assert level["k_reduce_popc"] == level["k_reduce_sum"] == 0
-    # the run-end tiles add up the tile sums themselves (no scan step for the runs); the ranks still have theirs
-    assert "k_rle_expand<8>" not in level and level["k_rle_ends"] == 1 and level["k_select_scatter<8>"] == 2
-    assert level["k_scan_tiles"] == 1
+    assert level["k_reduce_popc"] == level["k_rle_ends"] == 0
+    assert "k_rle_expand<8>" not in level and level["k_select_scatter<8>"] == 1
+    assert set(level) == {"k_reduce_popc", "k_rle_ends", "k_select_scatter<8>"}
     p.close()
     fused = Plan.from_encodings([enc])
-    assert int(fused.info.n_launches) == 3
+    assert int(fused.info.n_launches) == 2
     fused.close()
 
 
@@ -266,8 +265,8 @@ def test_values_children_resolved_inside_the_rank_scatter():
     assert "k_rle_expand<2>" in got and "k_select_scatter<2>" in got  # narrow rows: two passes
     mc = np.where(rng.random(nn) < 0.9, 7, rng.integers(100, 1000, nn)).astype(np.int64)
     got = names(E.encode_nullable(E.Nullable(data=E.MainlyConstant(), nulls=E.SparseBool()), mc, mask, W.INT64))
-    # both nodes count ranks, one scatters; SparseBool selections count while they build their bitmaps
-    assert got == ["k_sparse_bits", "k_scan_tiles", "k_select_scatter<8>"]
+    # both nodes count ranks, one scatters; SparseBool selections write them scanned while they build their bitmaps
+    assert got == ["k_sparse_bits", "k_select_scatter<8>"]
     got = names(E.encode_nullable(E.Nullable(data=E.MainlyConstant(is_common=E.Trivial()), nulls=E.SparseBool()), mc, mask, W.INT64))
     assert got.count("k_select_scatter<8>") == 1 and "k_reduce_popc" in got  # a plain bitmap is counted by a pass of its own
     # nesting goes one deep: of three MainlyConstants the middle one is resolved by the outermost, the innermost scatters itself
@@ -281,11 +280,11 @@ def test_bool_rle_root_expands_to_bytes_without_a_bitmap_step():
     expansion; under a Nullable it stays a bitmap for the select step."""
     b = np.repeat(np.arange(500) & 1, 77).astype(bool)
     p = Plan.from_encodings([E.encode(E.RLE(), b, W.BOOL)], per_kernel=True)
-    assert [l[0] for l in p.launches()] == ["k_rle_ends", "k_rle_expand_bool"]  # 500 runs: one tile, no sums to add up
+    assert [l[0] for l in p.launches()] == ["k_rle_ends", "k_rle_expand_bool"]  # 500 runs: one tile
     p.close()
-    many = np.repeat(np.arange(5000) & 1, 7).astype(bool)                      # 5,000 runs: three tiles
+    many = np.repeat(np.arange(5000) & 1, 7).astype(bool)                      # 5,000 runs: three tiles, chained
     p = Plan.from_encodings([E.encode(E.RLE(), many, W.BOOL)], per_kernel=True)
-    assert [l[0] for l in p.launches()] == ["k_reduce_sum", "k_rle_ends", "k_rle_expand_bool"]
+    assert [(l[0], l[2]) for l in p.launches()][:1] == [("k_rle_ends", 3)] and len(p.launches()) == 2
     p.close()
     mask = np.random.default_rng(9).random(60_000) < 0.5
     enc = E.encode_nullable(E.Nullable(data=E.RLE(), nulls=E.Trivial()), b[: int(mask.sum())], mask, W.BOOL)
@@ -338,7 +337,7 @@ def test_rle_without_rows_schedules_no_run_kernels(varint_rows):
     for per_kernel in (False, True):
         p = Plan.from_encodings(empty_rle_cases(varint_rows), varint_rows, per_kernel=per_kernel)
         names = {l[0] for l in p.launches()}
-        assert not any(n.startswith(("k_rle", "k_reduce_sum")) for n in names), names
+        assert not any(n.startswith("k_rle") for n in names), names
         assert [l.rows for l in p.layouts] == [0, 3000, 0]
         p.close()
 
