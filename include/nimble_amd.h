@@ -60,6 +60,11 @@ typedef struct nbl_options {
                                     * the level's fused launch); 0 = the library's default (32768, about
                                     * 0.5 GB of scattered output).  Read when struct_size >= 16.
                                     * No counterpart in the reference. */
+  uint32_t lds_dictionary_min_tiles; /* tiles of 8-byte dictionaries with 2,049 .. 4,096 entries in one cascade
+                                      * level from which the LDS-alphabet kernel gets a launch of its own (fewer
+                                      * are gathered from memory inside the fused launch); 0 = the library's
+                                      * default (4096).  Read when struct_size >= 20.  No counterpart in the
+                                      * reference. */
 } nbl_options;
 
 /* By default every cascade level of the batch is ONE kernel launch whose tiles
@@ -73,6 +78,10 @@ typedef struct nbl_options {
  * kernel; by default columns whose tiles stage few values take the one-wave
  * kernel (more tiles in flight per CU).  Same results; for tuning and tests. */
 #define NBL_PLAN_FOUR_WAVE_SCATTER 4u
+/* Gather every dictionary from memory; by default dictionaries of 8-byte rows
+ * (64-bit numbers, string views) with 2,049 .. 4,096 entries run on a kernel
+ * that keeps the alphabet in LDS.  Same results; for tuning and tests. */
+#define NBL_PLAN_NO_LDS_DICTIONARY 8u
 
 typedef struct nbl_plan nbl_plan;
 

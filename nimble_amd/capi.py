@@ -31,12 +31,13 @@ EXPORTED_SYMBOLS = (
 
 class NblOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("use_varint_row_count", C.c_uint32), ("flags", C.c_uint32),
-                ("wave_scatter_min_tiles", C.c_uint32)]
+                ("wave_scatter_min_tiles", C.c_uint32), ("lds_dictionary_min_tiles", C.c_uint32)]
 
 
 PLAN_PER_KERNEL_LAUNCHES = 1
 PLAN_KEEP_DICTIONARY = 2
 PLAN_FOUR_WAVE_SCATTER = 4
+PLAN_NO_LDS_DICTIONARY = 8
 
 
 class NblPlanInfo(C.Structure):

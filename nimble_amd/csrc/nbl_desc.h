@@ -55,6 +55,9 @@ enum KernelId : uint32_t {
   K_MATERIALIZE_RAW,   // root Trivial / byte-aligned FixedBitWidth: copy (+ baseline)
   K_FRAME_UNPACK,      // BlockBitPacking blocks / FOR frames: per-segment baseline + width
   K_SELECT_SCATTER_WAVE,  // Nullable / MainlyConstant of 4- / 8-byte rows with few values per tile: one wave per tile
+  K_DICT_LDS,             // Dictionary of 8-byte rows (numbers, string views) whose alphabet fits kDictLdsEntries but not
+                          // the fused launch's stage, alone or gathered inside a rank scatter (NF_DICT_VALUES): the
+                          // alphabet sits in LDS and one workgroup runs kDictLdsTiles tiles against it
   K_COUNT,
   // Launch ids of the fused launches: one launch runs every step of a cascade
   // level, each tile naming its own operation (TileRef::tile, high byte).
@@ -73,14 +76,15 @@ constexpr uint32_t make_op(uint32_t kernel, uint32_t es) { return kernel * 4u + 
 constexpr bool kernel_has_es(uint32_t k) {
   return k == K_MATERIALIZE || k == K_MATERIALIZE_FBW || k == K_MATERIALIZE_RAW || k == K_RLE_EXPAND ||
          k == K_SELECT_SCATTER || k == K_DICT_GATHER || k == K_VARINT_DECODE || k == K_FRAME_UNPACK ||
-         k == K_SELECT_SCATTER_WAVE;
+         k == K_SELECT_SCATTER_WAVE || k == K_DICT_LDS;
 }
 // Operations the fused level launch carries.  The block encodings are rare
 // (experimental in the reference) and their body would cost the fused kernel
 // registers it does not have to spare, so they keep a launch of their own.
 // The one-wave rank scatter is a launch of its own by construction: 64-thread
 // workgroups with a quarter of the LDS, so that a CU holds 32 of its tiles.
-constexpr bool kernel_is_fusable(uint32_t k) { return k != K_FRAME_UNPACK && k != K_SELECT_SCATTER_WAVE; }
+// So is the LDS-alphabet dictionary kernel: 40 KiB of LDS per workgroup.
+constexpr bool kernel_is_fusable(uint32_t k) { return k != K_FRAME_UNPACK && k != K_SELECT_SCATTER_WAVE && k != K_DICT_LDS; }
 constexpr uint32_t op_of(uint32_t kernel, uint32_t es) { return make_op(kernel, kernel_has_es(kernel) ? es : 1u); }
 
 enum NodeFlags : uint32_t {
@@ -183,6 +187,10 @@ constexpr uint32_t select_tile_rows(uint32_t es) { return kTileBytes / es; }
 // bytes of staged values a tile may need (a tile that needs more reads them
 // from memory row by row; the planner picks the kernel by the column's average).
 constexpr uint32_t kWaveBlock = 64;
+// K_DICT_LDS: alphabet entries (8 bytes each) the kernel keeps in LDS, and the
+// 16 KiB tiles one workgroup decodes against them (the 32 KiB copy is paid once).
+constexpr uint32_t kDictLdsEntries = 4096;
+constexpr uint32_t kDictLdsTiles = 8;
 constexpr uint32_t kWaveStageBytes = 2432;
 
 }  // namespace nbl

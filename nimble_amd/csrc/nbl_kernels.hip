@@ -2369,6 +2369,126 @@ __device__ __forceinline__ void body_dict_gather(const KArgs& a, const NodeDesc&
   if (bad) atomicOr(a.status, ST_DICT_INDEX_RANGE);
 }
 
+// ---------------------------------------------------------------- K_DICT_LDS
+// The same gather -- alone (c0 = indices, c1 = alphabet) or inside a rank
+// scatter (NF_DICT_VALUES: c0 = alphabet, c1 = indices of the selected rows) --
+// for 8-byte rows whose alphabet has more entries than the fused launch can
+// stage (2,048) and at most kDictLdsEntries.  From memory every row of such a
+// column costs the vector L1 a 128-byte line fill for its 8 bytes; here the
+// alphabet is copied to LDS once per workgroup, which then runs kDictLdsTiles
+// consecutive tiles of the node against it.  Three workgroups fit a CU, so the
+// loads of the next tile (bitmap word, staged indices) are issued before the
+// current tile is gathered: two tiles per workgroup are in flight.
+constexpr uint32_t kDictLdsAlphaBytes = kDictLdsEntries * 8;
+constexpr uint32_t kDictLdsStageBytes = ((15 + (kTileBytes / 8 * 4 + 1) + 4 + 15) >> 4) * 16;  // 2,048 staged indices of up to 32 bits
+constexpr uint32_t kDictLdsSmemBytes = kDictLdsAlphaBytes + kDictLdsStageBytes + 32 * 8 + 64 * 2 + 64;
+static_assert(kDictLdsSmemBytes * 3 <= 160 * 1024 && kDictLdsStageBytes <= 3 * kBlock * 16, "three workgroups per CU; StageRegs<3> cover the stage");
+
+__device__ __forceinline__ void body_dict_lds(const KArgs& a, const NodeDesc& nd, uint32_t group, uint8_t* smem, uint32_t pslot0) {
+  using T = uint64_t;
+  constexpr int ES = 8;
+  constexpr uint32_t V = 2, TE = kTileBytes / ES, W = TE / 64;
+  const bool scatter = (nd.flags & NF_DICT_VALUES) != 0;
+  const ColRef& aref = scatter ? nd.c0 : nd.c1;
+  const ColRef& iref = scatter ? nd.c1 : nd.c0;
+  const uint32_t A = aref.rows;  // 1 .. kDictLdsEntries: the planner's choice
+  const uint64_t rows = nd.rows;
+  const uint32_t n_tiles = (uint32_t)((rows + TE - 1) / TE);
+  const uint32_t t_begin = group * kDictLdsTiles;
+  const uint32_t t_end = t_begin + kDictLdsTiles < n_tiles ? t_begin + kDictLdsTiles : n_tiles;
+  T* s_alpha = reinterpret_cast<T*>(smem);
+  uint8_t* s_stage = smem + kDictLdsAlphaBytes;
+  uint64_t* s_bits = reinterpret_cast<uint64_t*>(s_stage + kDictLdsStageBytes);
+  uint16_t* s_pref = reinterpret_cast<uint16_t*>(s_bits + W);
+  const uint32_t* bits32 = reinterpret_cast<const uint32_t*>(s_bits);
+  const bool invert = (nd.flags & NF_INVERT_SEL) != 0;
+  const uint32_t nvals = iref.rows;
+  const T fill = (T)nd.aux;
+  if (scatter && group == 0 && threadIdx.x == 0 && sload32(a.totals + nd.total_idx) != nvals) atomicOr(a.status, ST_SELECT_COUNT);
+  {  // the alphabet: every load of a thread in flight together
+    const Reader<RK_PTR, ES> alpha(aref, a);
+    constexpr uint32_t PER = kDictLdsEntries / kBlock;
+    T e[PER];
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) {
+      const uint32_t j = u * kBlock + threadIdx.x;
+      e[u] = alpha.get(j < A ? j : A - 1);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < PER; ++u) {
+      const uint32_t j = u * kBlock + threadIdx.x;
+      if (j < A) s_alpha[j] = e[u];
+    }
+  }
+  const uint32_t amax = A - 1;
+  bool bad = false;
+  with_reader<4>(iref, a, [&](auto rd) {
+    StageRegs<3> regs;
+    uint32_t bit0 = 0, n = 0;
+    uint64_t word = 0;
+    // requests everything tile t reads from memory: its bitmap word and its indices
+    auto fetch = [&](uint32_t t) {
+      const uint64_t p0 = (uint64_t)t * TE;
+      uint64_t first;
+      if (scatter) {
+        const uint32_t base = sload32(a.parts + pslot0 + (t - t_begin));
+        const uint32_t next = sload32(a.parts + pslot0 + (t - t_begin) + 1);  // the node's total sits behind its last partial
+        const uint32_t count = next - base < TE ? next - base : TE;
+        const uint32_t avail = base < nvals ? nvals - base : 0u;
+        n = count < avail ? count : avail;  // counts that disagree with the values child are clamped, never followed
+        first = base;
+        const uint64_t w = (uint64_t)t * W + threadIdx.x;
+        word = 0;
+        if (threadIdx.x < W && w * 64 < rows) word = BitsReader(nd.sel, a, invert).word(w);
+      } else {
+        n = rows - p0 < TE ? (uint32_t)(rows - p0) : TE;
+        first = p0;
+      }
+      regs.nvec = 0;
+      bit0 = 0;
+      if (n) bit0 = rd.template stage_begin<3>(first, n, regs);
+    };
+    fetch(t_begin);
+    for (uint32_t t = t_begin; t < t_end; ++t) {  // workgroup uniform
+      const uint64_t p0 = (uint64_t)t * TE;
+      const uint32_t tile_rows = rows - p0 < TE ? (uint32_t)(rows - p0) : TE;
+      T* dst = reinterpret_cast<T*>(self_ptr(nd, a)) + p0;
+      const uint32_t cur_n = n;
+      const auto idxs = rd.template stage_end<3>(regs, bit0, s_stage);
+      if (scatter) {
+        const uint64_t w = (uint64_t)t * W + threadIdx.x;
+        if ((nd.flags & NF_WRITE_NULLS) && threadIdx.x < W && w * 64 < rows)
+          reinterpret_cast<uint64_t*>(a.out + nd.aux_off)[w] = invert ? ~word & (w * 64 + 64 > rows ? wmask((uint32_t)(rows - w * 64)) : ~0ull) : word;
+        tile_rank_scan32<W>(word, s_bits, s_pref, nullptr);
+      }
+      __syncthreads();
+      if (t + 1 < t_end) fetch(t + 1);  // in flight while this tile is gathered
+      const uint32_t last = cur_n ? cur_n - 1 : 0u;
+#pragma unroll
+      for (uint32_t it = 0; it < 4; ++it) {
+        const uint32_t q0 = (it * kBlock + threadIdx.x) * V;
+        uint32_t r = q0, sel = (1u << V) - 1u;
+        if (scatter) vector_ranks<V>(bits32, s_pref, q0, r, sel);
+        if (cur_n == 0) sel = 0;  // nothing staged: every row takes the fill
+        Vec16<ES> o;
+#pragma unroll
+        for (uint32_t j = 0; j < V; ++j) {
+          const uint32_t rj = scatter ? r + (uint32_t)__popc(sel & ((1u << j) - 1u)) : q0 + j;
+          uint32_t i = idxs.at(rj < last ? rj : last);
+          if (i > amax) {
+            bad |= ((sel >> j) & 1u) != 0 && q0 + j < tile_rows;
+            i = amax;
+          }
+          o.v[j] = pick<T>(sel, j, s_alpha[i], fill);
+        }
+        store_vec_padded<ES>(dst, q0, tile_rows, o);
+      }
+      __syncthreads();  // the stage and the bitmap words are the next tile's
+    }
+  });
+  if (bad) atomicOr(a.status, ST_DICT_INDEX_RANGE);
+}
+
 // ----------------------------------------------------------- K_VARINT_DECODE
 // VarintEncoding::materialize (encodings/VarintEncoding.h:119-140): LEB128,
 // low 7 bits first, + baseline (common/Varint.h:83-143 for the byte limits).
@@ -2845,6 +2965,15 @@ __device__ __forceinline__ KArgs load_args(KArgsSegment k) {
   return a;
 }
 
+__global__ __launch_bounds__(kBlock, 3) void k_dict_lds(KArgs a) {
+  __shared__ __align__(16) uint8_t smem[kDictLdsSmemBytes];
+  const uint32_t node = sload32(&a.tiles[blockIdx.x].node);
+  const uint32_t group = sload32(&a.tiles[blockIdx.x].tile) & kTileMask;
+  const uint32_t aux = sload32(a.tile_aux + blockIdx.x);
+  const NodeDesc nd = load_node(a.nodes + node);
+  body_dict_lds(a, nd, group, smem, aux);
+}
+
 template <bool LAST>
 __global__ __launch_bounds__(256, 8) void k_level(KArgs) {
   __shared__ __align__(16) uint8_t smem[kSmemBytes + kPhaseBytes];
@@ -2940,6 +3069,10 @@ extern "C" int nbl_launch_kernel(uint32_t kernel, uint32_t es, const nbl::KArgs*
       if (es == 4) hipLaunchKernelGGL(k_select_scatter_wave<4>, grid, dim3(kWaveBlock), 0, s, a);
       else if (es == 8) hipLaunchKernelGGL(k_select_scatter_wave<8>, grid, dim3(kWaveBlock), 0, s, a);
       else return -1;
+      break;
+    case K_DICT_LDS:
+      if (es != 8) return -1;
+      hipLaunchKernelGGL(k_dict_lds, grid, block, 0, s, a);
       break;
     default: return -1;
   }

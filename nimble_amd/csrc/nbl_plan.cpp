@@ -117,6 +117,9 @@ constexpr uint32_t kWholeMaxPositions = 4096, kWholeMaxPositionsBatch = 32768;
 // Rank-scatter tiles of one level (16 KiB of output each) from which the one-wave
 // kernel gets its own launch; a launch of one element size needs an eighth of that.
 constexpr uint64_t kWaveLaunchMinTiles = 32768;
+// Tiles (16 KiB of output each) of 2,049 .. 4,096-entry dictionaries of one level
+// from which the LDS-alphabet kernel gets its launch.
+constexpr uint64_t kLdsDictMinTiles = 4096;
 
 struct Step {
   int level;
@@ -142,7 +145,7 @@ struct Launch {
 const char* kKernelNames[K_COUNT] = {
     "k_materialize", "k_bits_to_bytes", "k_reduce_popc", "k_rle_ends", "k_rle_expand", "k_rle_expand_bool", "k_sparse_bits",
     "k_select_scatter", "k_dict_gather", "k_varint_decode", "k_string_views", "k_copy_bytes",
-    "k_select_bits", "k_materialize_fbw", "k_materialize_raw", "k_frame_unpack", "k_select_scatter_wave"};
+    "k_select_bits", "k_materialize_fbw", "k_materialize_raw", "k_frame_unpack", "k_select_scatter_wave", "k_dict_lds"};
 
 }  // namespace
 
@@ -165,6 +168,8 @@ struct nbl_plan {
   bool keep_dictionary = false;  // also emit alphabet + indices of dictionary chunks
   bool fused = true;          // one launch per cascade level (default) or one per (level, kernel, element size)
   bool wave_scatter = true;   // sparse rank scatters on the one-wave kernel (default) or every one on the four-wave tile
+  bool lds_dictionary = true; // 8-byte dictionaries of 2,049 .. 4,096 entries on the LDS-alphabet kernel (default) or gathered from memory
+  uint64_t lds_dict_min_tiles = kLdsDictMinTiles;  // tiles of such dictionaries in one level that make a launch of that kernel
   uint64_t wave_min_tiles = kWaveLaunchMinTiles;  // tiles of one level and element size that make a one-wave launch
   int cur_chunk = -1;         // chunk being planned
   std::vector<uint8_t> blob;  // NodeDesc[] | TileRef[] image uploaded to work
@@ -768,7 +773,13 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       d.self = mat_ref(es);
       d.rows = rows;
       const uint32_t dn = add_dnode(d);
-      add_step(lvl, K_DICT_GATHER, es, dn, div_up32(rows, tile_rows));
+      // 8-byte rows over an alphabet that the fused launch cannot stage (more than
+      // kTileBytes of entries) but kDictLdsEntries hold: the LDS-alphabet kernel,
+      // one workgroup per kDictLdsTiles tiles
+      if (lds_dictionary && es == 8 && C(0).rows > kTileBytes / 8 && C(0).rows <= kDictLdsEntries)
+        add_step(lvl, K_DICT_LDS, es, dn, div_up32(div_up32(rows, tile_rows), kDictLdsTiles));
+      else
+        add_step(lvl, K_DICT_GATHER, es, dn, div_up32(rows, tile_rows));
       nn.ref = d.self; nn.ready = lvl + 1;
       break;
     }
@@ -861,7 +872,9 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
         const uint64_t bits = v.kind == COL_CONST ? 0u : (v.kind == COL_FBW ? v.width : 8u * es);
         one_wave = (uint64_t)v.rows * bits / 8 * trows * 3 <= (uint64_t)kWaveStageBytes * 2 * rows;
       }
+      const bool lds_dict = lds_dictionary && (d.flags & NF_DICT_VALUES) && es == 8 && d.c0.rows > kTileBytes / 8 && d.c0.rows <= kDictLdsEntries;
       if (nn.is_bool) add_step(fin, K_SELECT_BITS, 0, dn, nt);
+      else if (lds_dict) add_step(fin, K_DICT_LDS, es, dn, div_up32(nt, kDictLdsTiles));
       else add_step(fin, one_wave ? K_SELECT_SCATTER_WAVE : K_SELECT_SCATTER, es, dn, nt);
       nn.ref = d.self; nn.ready = fin + 1;
       break;
@@ -1086,6 +1099,23 @@ void nbl_plan::finish() {
            wave_tiles[(size_t)st.level * 4 + es_slot(st.es)] * 8 < wave_min_tiles))
         st.kernel = K_SELECT_SCATTER;
   }
+  {
+    // The LDS-alphabet dictionary kernel is a launch of its own as well (40 KiB of
+    // LDS per workgroup).  Alone it runs at the rate its bytes move (5.5 TB/s
+    // against 4.1-4.4 for the same columns gathered from memory), but a launch
+    // costs its ramp and tail and what its tiles would have hidden inside the
+    // fused launch: below lds_dict_min_tiles tiles of a level the nodes keep the
+    // fused launch's gather.
+    std::vector<uint64_t> lds_tiles((size_t)last_level + 1, 0);
+    auto tiles_of = [&](const Step& st) { return (uint64_t)div_up32(dnodes[st.dnode].rows, kTileBytes / 8); };
+    for (const Step& st : steps)
+      if (st.kernel == K_DICT_LDS) lds_tiles[(size_t)st.level] += tiles_of(st);
+    for (Step& st : steps)
+      if (st.kernel == K_DICT_LDS && lds_tiles[(size_t)st.level] < lds_dict_min_tiles) {
+        st.kernel = (dnodes[st.dnode].flags & NF_DICT_VALUES) ? K_SELECT_SCATTER : K_DICT_GATHER;
+        st.n_tiles = (uint32_t)tiles_of(st);
+      }
+  }
   if (fused && last_level > 0) spread_free_steps(last_level);
   {  // stable counting sort by (level, filler, kernel, element size): wide tables have ~10 steps per column
     // within a level: the level's own fusable steps, the fillers, then the steps that launch on their own
@@ -1143,19 +1173,46 @@ void nbl_plan::finish() {
     size_t j = i;
     Launch L{steps[i].kernel, steps[i].es, (uint32_t)tiles.size(), 0, steps[i].level, 0, std::string()};
     const bool fuse = fused && kernel_is_fusable(steps[i].kernel);
+    size_t first_filler = tiles.size();  // where the level's filler tiles start in the table
+    bool fillers = false;
     while (j < steps.size() && steps[j].level == steps[i].level &&
            (fuse ? kernel_is_fusable(steps[j].kernel) : (steps[j].kernel == steps[i].kernel && steps[j].es == steps[i].es))) {
       const uint32_t op = op_of(steps[j].kernel, steps[j].es) << kOpShift;
-      const bool scatter = steps[j].kernel == K_SELECT_SCATTER || steps[j].kernel == K_SELECT_SCATTER_WAVE;
+      const bool lds_dict = steps[j].kernel == K_DICT_LDS;  // an entry is a group of kDictLdsTiles tiles
+      const bool scatter = steps[j].kernel == K_SELECT_SCATTER || steps[j].kernel == K_SELECT_SCATTER_WAVE ||
+                           (lds_dict && (dnodes[steps[j].dnode].flags & NF_DICT_VALUES));
       const uint32_t aux_base = scatter ? dnodes[steps[j].dnode].part_base : 0u;
+      if (steps[j].filler && !fillers) { fillers = true; first_filler = tiles.size(); }
       for (uint32_t t = 0; t < steps[j].n_tiles; ++t) {
         tiles.push_back(TileRef{steps[j].dnode, op | (steps[j].tile_begin + t)});
-        tile_aux.push_back(scatter ? aux_base + steps[j].tile_begin + t : 0u);
+        tile_aux.push_back(scatter ? aux_base + (steps[j].tile_begin + t) * (lds_dict ? kDictLdsTiles : 1u) : 0u);
       }
       L.alg_bytes += steps[j].alg;
       ++j;
     }
     L.n_tiles = (uint32_t)tiles.size() - L.tile_begin;
+    if (fuse && fillers && first_filler > L.tile_begin) {
+      // The level's own tiles (chained scans, bitmap builds: each a chain of trips
+      // to memory) hold a workgroup slot for several times as long as a filler
+      // tile moves its 16 KiB.  Launched first they fill every slot of the chip
+      // and the fillers' bandwidth waits for them; dealt out among the fillers
+      // over the first three quarters of the launch, both run side by side.
+      const size_t n_own = first_filler - L.tile_begin, n_fill = tiles.size() - first_filler;
+      const size_t span = std::max(n_own, (n_own + n_fill) * 3 / 4);  // table slots the own tiles are spread over
+      std::vector<TileRef> merged;
+      std::vector<uint32_t> merged_aux;
+      merged.reserve(n_own + n_fill);
+      merged_aux.reserve(n_own + n_fill);
+      size_t o = 0, f = 0;
+      for (size_t pos = 0; pos < n_own + n_fill; ++pos) {
+        const bool own = o < n_own && (f >= n_fill || o * span <= pos * n_own);
+        const size_t src = own ? L.tile_begin + o++ : first_filler + f++;
+        merged.push_back(tiles[src]);
+        merged_aux.push_back(tile_aux[src]);
+      }
+      std::copy(merged.begin(), merged.end(), tiles.begin() + (ptrdiff_t)L.tile_begin);
+      std::copy(merged_aux.begin(), merged_aux.end(), tile_aux.begin() + (ptrdiff_t)L.tile_begin);
+    }
     if (fuse) {
       L.kernel = L.level == last_level ? K_LEVEL_LAST : K_LEVEL;
       L.es = 0;
@@ -1254,7 +1311,9 @@ nbl_status nbl_plan_batch(const uint8_t* base, const uint64_t* offsets, const ui
     p->fused = !(options && options->struct_size >= 12 && (options->flags & NBL_PLAN_PER_KERNEL_LAUNCHES));
     p->keep_dictionary = options && options->struct_size >= 12 && (options->flags & NBL_PLAN_KEEP_DICTIONARY);
     p->wave_scatter = !(options && options->struct_size >= 12 && (options->flags & NBL_PLAN_FOUR_WAVE_SCATTER));
+    p->lds_dictionary = !(options && options->struct_size >= 12 && (options->flags & NBL_PLAN_NO_LDS_DICTIONARY));
     if (options && options->struct_size >= 16 && options->wave_scatter_min_tiles) p->wave_min_tiles = options->wave_scatter_min_tiles;
+    if (options && options->struct_size >= 20 && options->lds_dictionary_min_tiles) p->lds_dict_min_tiles = options->lds_dictionary_min_tiles;
     p->layouts.resize(n_chunks);
     for (uint32_t c = 0; c < n_chunks; ++c) {
       if (offsets[c] + sizes[c] < offsets[c]) fail(NBL_ERR_ARGUMENT, "chunk %u: offset + size overflows", c);

@@ -32,12 +32,16 @@ class Plan:
     """nbl_plan_batch over chunks stored in one host buffer."""
 
     def __init__(self, buffer, chunks: Sequence[tuple[int, int]], varint_rows: bool = False, per_kernel: bool = False,
-                 keep_dictionary: bool = False, four_wave_scatter: bool = False, wave_scatter_min_tiles: int = 0):
+                 keep_dictionary: bool = False, four_wave_scatter: bool = False, wave_scatter_min_tiles: int = 0,
+                 no_lds_dictionary: bool = False, lds_dictionary_min_tiles: int = 0):
         """per_kernel: one launch per (level, operation) instead of one fused
         launch per cascade level -- for profiling, same results.
         four_wave_scatter: no rank scatter on the one-wave kernel -- same results.
         wave_scatter_min_tiles: tiles of a level from which the one-wave kernel is
-        launched (0: the library's default)."""
+        launched (0: the library's default).
+        no_lds_dictionary: every dictionary gathered from memory -- same results.
+        lds_dictionary_min_tiles: tiles of a level from which the LDS-alphabet dictionary
+        kernel is launched (0: the library's default)."""
         self.buffer = capi.as_u8(buffer)
         self.chunks = [(int(o), int(s)) for o, s in chunks]
         n = len(self.chunks)
@@ -49,7 +53,9 @@ class Plan:
         opts = capi.NblOptions(C.sizeof(capi.NblOptions), int(varint_rows),
                                (capi.PLAN_PER_KERNEL_LAUNCHES if per_kernel else 0) |
                                (capi.PLAN_KEEP_DICTIONARY if keep_dictionary else 0) |
-                               (capi.PLAN_FOUR_WAVE_SCATTER if four_wave_scatter else 0), int(wave_scatter_min_tiles))
+                               (capi.PLAN_FOUR_WAVE_SCATTER if four_wave_scatter else 0) |
+                               (capi.PLAN_NO_LDS_DICTIONARY if no_lds_dictionary else 0), int(wave_scatter_min_tiles),
+                               int(lds_dictionary_min_tiles))
         handle = C.c_void_p()
         capi.check(capi.lib().nbl_plan_batch(self.buffer.ctypes.data, offs.ctypes.data, sizes.ctypes.data, n,
                                              C.byref(opts), C.byref(handle)))
@@ -66,7 +72,8 @@ class Plan:
     @staticmethod
     def from_encodings(encodings: Sequence[bytes], varint_rows: bool = False, per_kernel: bool = False,
                        keep_dictionary: bool = False, four_wave_scatter: bool = False,
-                       wave_scatter_min_tiles: int = 0) -> "Plan":
+                       wave_scatter_min_tiles: int = 0, no_lds_dictionary: bool = False,
+                       lds_dictionary_min_tiles: int = 0) -> "Plan":
         """Concatenates standalone encodings (16-byte aligned starts are NOT
         required; they are packed back to back on purpose)."""
         offs, pos = [], 0
@@ -74,7 +81,8 @@ class Plan:
             offs.append((pos, len(e)))
             pos += len(e)
         buf = np.frombuffer(b"".join(bytes(e) for e in encodings), dtype=np.uint8) if encodings else np.zeros(0, np.uint8)
-        return Plan(buf, offs, varint_rows, per_kernel, keep_dictionary, four_wave_scatter, wave_scatter_min_tiles)
+        return Plan(buf, offs, varint_rows, per_kernel, keep_dictionary, four_wave_scatter, wave_scatter_min_tiles,
+                    no_lds_dictionary, lds_dictionary_min_tiles)
 
     def launches(self):
         """[(kernel, elem_bytes, n_tiles, level, alg_bytes)] in launch order."""
@@ -198,10 +206,12 @@ def slice_chunk(host_out: np.ndarray, lay) -> ChunkResult:
 
 def decode_encodings(encodings: Sequence[bytes], varint_rows: bool = False, device: str = "cuda:0",
                      per_kernel: bool = False, four_wave_scatter: bool = False,
-                     wave_scatter_min_tiles: int = 0) -> list[ChunkResult]:
+                     wave_scatter_min_tiles: int = 0, no_lds_dictionary: bool = False,
+                     lds_dictionary_min_tiles: int = 0) -> list[ChunkResult]:
     """Convenience: plan + stage + decode + status + fetch for standalone encodings."""
     plan = Plan.from_encodings(encodings, varint_rows, per_kernel, four_wave_scatter=four_wave_scatter,
-                               wave_scatter_min_tiles=wave_scatter_min_tiles)
+                               wave_scatter_min_tiles=wave_scatter_min_tiles, no_lds_dictionary=no_lds_dictionary,
+                               lds_dictionary_min_tiles=lds_dictionary_min_tiles)
     dec = BatchDecoder(plan, device)
     dec.stage()
     dec.decode()

@@ -167,7 +167,8 @@ def test_fused_and_per_operation_plans_agree_on_layout_and_bytes():
 
     chunks = WL.mixed_table_stripe(stripe=1, rows=3000)
     buf, offs = WL.pack_chunks(chunks)
-    fused, per_op = Plan(buf, offs, four_wave_scatter=True), Plan(buf, offs, per_kernel=True, four_wave_scatter=True)
+    only_fused = dict(four_wave_scatter=True, no_lds_dictionary=True)  # no kernel that is a launch of its own
+    fused, per_op = Plan(buf, offs, **only_fused), Plan(buf, offs, per_kernel=True, **only_fused)
     assert fused.info.out_bytes == per_op.info.out_bytes and fused.info.work_bytes == per_op.info.work_bytes
     for a, b in zip(fused.layouts, per_op.layouts):
         assert bytes(a) == bytes(b)
@@ -182,10 +183,10 @@ def test_fused_and_per_operation_plans_agree_on_layout_and_bytes():
     # of its own behind the fused launch of its level (by default only where a
     # level has tens of thousands of such tiles): same outputs, same tiles and
     # bytes, one fused launch per level as before.
-    small = Plan(buf, offs)
+    small = Plan(buf, offs, no_lds_dictionary=True)
     assert {l[0] for l in small.launches()} <= {"k_level<false>", "k_level<true>"}
     small.close()
-    dflt = Plan(buf, offs, wave_scatter_min_tiles=1)
+    dflt = Plan(buf, offs, wave_scatter_min_tiles=1, no_lds_dictionary=True)
     assert dflt.info.out_bytes == fused.info.out_bytes
     for a, b in zip(dflt.layouts, fused.layouts):
         assert bytes(a) == bytes(b)

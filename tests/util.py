@@ -154,17 +154,18 @@ def check_parity(O, encodings, varint_rows: bool = False, labels=None):
     """Decode all encodings in ONE GPU batch and compare each with the oracle."""
     from nimble_amd.decoder import decode_encodings
 
-    # one tile is enough for the one-wave rank scatter to get its launch: the test inputs are small
-    results = decode_encodings(encodings, varint_rows, wave_scatter_min_tiles=1)
+    # one tile is enough for the one-wave rank scatter and the LDS-alphabet dictionary kernel to get their
+    # launches: the test inputs are small
+    results = decode_encodings(encodings, varint_rows, wave_scatter_min_tiles=1, lds_dictionary_min_tiles=1)
     assert len(results) == len(encodings)
     # the same batch with one launch per operation instead of one per level
     unfused = decode_encodings(encodings, varint_rows, per_kernel=True)
-    # and with every rank scatter on the four-wave tile kernel
-    four_wave = decode_encodings(encodings, varint_rows, four_wave_scatter=True)
+    # and with every rank scatter on the four-wave tile kernel and every dictionary gathered from memory
+    four_wave = decode_encodings(encodings, varint_rows, four_wave_scatter=True, no_lds_dictionary=True)
     for i, (enc, res) in enumerate(zip(encodings, results)):
         label = labels[i] if labels else f"chunk {i}"
         ora = oracle_chunk(O, enc, varint_rows)
         assert_chunk_equal(res, ora, label)
         assert_chunk_equal(unfused[i], ora, label + " (per-operation launches)")
-        assert_chunk_equal(four_wave[i], ora, label + " (four-wave rank scatter)")
+        assert_chunk_equal(four_wave[i], ora, label + " (four-wave rank scatter, dictionaries from memory)")
     return results
