@@ -301,22 +301,31 @@ def pcie_pipelined(plan, torch, device, n_buffers=2, stripes=8):
 class Job:
     """The stripes one rank owns, planned and resident on its GPU."""
 
-    def __init__(self, workload, rows, stripe_ids, device, per_kernel=False, keep_chunks=False):
+    def __init__(self, workload, rows, stripe_ids, device, per_kernel=False, keep_chunks=False, packed=None, **plan_options):
+        """packed: [(buffer, offsets)] of stripes generated before (then nothing is generated here)."""
         from nimble_amd import workloads
         from nimble_amd.decoder import BatchDecoder, Plan
 
-        self.plans, self.decs, self.chunks = [], [], []
+        self.plans, self.decs, self.chunks, self.packed = [], [], [], []
         t0 = time.perf_counter()
-        for s in stripe_ids:
-            chunks = workloads.WORKLOADS[workload](rows, 42 + s)
-            buf, offs = workloads.pack_chunks(chunks)
-            plan = Plan(buf, offs, per_kernel=per_kernel)
+        for i, s in enumerate(stripe_ids):
+            if packed is not None:
+                chunks, (buf, offs) = None, packed[i]
+            else:
+                chunks = workloads.WORKLOADS[workload](rows, 42 + s)
+                buf, offs = workloads.pack_chunks(chunks)
+            plan = Plan(buf, offs, per_kernel=per_kernel, **plan_options)
             dec = BatchDecoder(plan, str(device))
             dec.stage()
             self.plans.append(plan)
             self.decs.append(dec)
             self.chunks.append(chunks if keep_chunks else None)
+            self.packed.append((buf, offs))
         self.gen_seconds = time.perf_counter() - t0
+        # host cost in front of a stripe's first launch: the header walk + scheduling
+        # (nbl_plan_batch) and the descriptor upload (nbl_plan_upload), per stripe
+        self.plan_ms = sum(p.plan_seconds for p in self.plans) * 1e3 / max(len(self.plans), 1)
+        self.upload_ms = sum(d.upload_seconds for d in self.decs) * 1e3 / max(len(self.decs), 1)
         self.decoded = sum(int(p.info.decoded_bytes) for p in self.plans)
         self.encoded = sum(int(p.info.encoded_bytes) for p in self.plans)
         self.rows = sum(int(p.info.total_rows) for p in self.plans)
@@ -393,6 +402,35 @@ def roofline_of(by, workload, rows, launches_per_step_of=1):
     return roofline
 
 
+def cold_steps(job, torch, device, steps=5, flush_bytes=1 << 30):
+    """Mean device time of a decode whose inputs are not in any cache: between
+    steps 1 GiB is written (four times the 256 MB memory-side cache), outside the
+    events that bracket each decode.  A reader decodes every stripe once, so this
+    is its case; the steady-state loop re-decodes one resident stripe."""
+    flush = torch.empty(flush_bytes, dtype=torch.uint8, device=device)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    flush.fill_(1)
+    for a, b in evs:
+        a.record()
+        job.decode()
+        b.record()
+        flush.fill_(2)
+    torch.cuda.synchronize(device)
+    del flush
+    return sum(a.elapsed_time(b) for a, b in evs) / steps
+
+
+def plan_fields(job, ms_per_step, cold_ms=None):
+    """Host planning cost per stripe and the decoded rate of a consumer that pays
+    it in front of every decode (single host thread, nothing overlapped)."""
+    stripes = max(len(job.plans), 1)
+    per_stripe_decode_ms = (cold_ms if cold_ms is not None else ms_per_step) / stripes
+    total_ms = job.plan_ms + job.upload_ms + per_stripe_decode_ms
+    return {"plan_ms": round(job.plan_ms + job.upload_ms, 3), "plan_batch_ms": round(job.plan_ms, 3),
+            "plan_upload_ms": round(job.upload_ms, 3),
+            "decoded_gbs_incl_plan": round(job.decoded / stripes / (total_ms * 1e-3) / 1e9, 2)}
+
+
 def short_run(workload, rows, device, torch, steps=5, warmup=2):
     """One of the other benchmark tables, outside the headline's timed region:
     `steps` passes over one stripe, wall clock between device synchronisations,
@@ -415,14 +453,36 @@ def short_run(workload, rows, device, torch, steps=5, warmup=2):
     job.status()
     by = by_kernel(job.launch_list, ms)
     whole = (job.encoded + job.decoded) / (sum(ms) * 1e-3) / 1e9 if sum(ms) > 0 else 0.0
+    cold_ms = cold_steps(job, torch, device, steps)
+    job.status()
     res = {
         "workload": WORKLOAD_TEXT[workload].format(rows=rows), "value": round(job.decoded / dt / 1e9, 2), "unit": "GB/s",
         "ms_per_step": round(dt * 1e3, 4), "steps": steps, "rows_per_s": round(job.rows / dt),
         "decoded_bytes": job.decoded, "encoded_bytes": job.encoded, "chunks": len(job.plans[0].layouts),
         "launches_per_step": len(job.launch_list),
         "whole_batch_algorithmic_gbs": round(whole, 1), "whole_batch_hbm_frac": round(whole / HBM_PEAK_GBS, 4),
+        "cold_ms_per_step": round(cold_ms, 4), "cold_value": round(job.decoded / (cold_ms * 1e-3) / 1e9, 2),
+        "cold_whole_batch_hbm_frac": round((job.encoded + job.decoded) / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         "roofline": roofline_of(by, workload, rows), "kernels": kernel_table(by), "gen_seconds": round(job.gen_seconds, 1),
     }
+    res.update(plan_fields(job, dt * 1e3, cold_ms))
+    if workload == "wide":
+        # the one-wave rank scatter's launch bound (nbl_options.wave_scatter_min_tiles) sides with
+        # the cold case: the same stripe with every rank scatter on the four-wave tiles, cold and warm
+        packed = job.packed
+        job.close()
+        job = Job(workload, rows, [0], device, packed=packed, four_wave_scatter=True)
+        for _ in range(warmup):
+            job.decode()
+        job.status()
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for s in range(steps):
+            job.decode()
+        torch.cuda.synchronize(device)
+        res["four_wave_only"] = {"ms_per_step": round((time.perf_counter() - t0) / steps * 1e3, 4),
+                                 "cold_ms_per_step": round(cold_steps(job, torch, device, steps), 4)}
+        job.status()
     job.close()
     return res
 
@@ -541,8 +601,16 @@ def main():
         "kernels": kernel_table(by),
         "gen_seconds": round(job.gen_seconds, 1),
     }
+    if owned:
+        result.update(plan_fields(job, ms_per_step))
 
     solo = rank == 0 and n_gpus == 1 and len(job.plans) == 1
+    if solo:
+        cold_ms = cold_steps(job, torch, device, 5)
+        job.status()
+        result["cold_ms_per_step"] = round(cold_ms, 4)
+        result["cold_value"] = round(job.decoded / (cold_ms * 1e-3) / 1e9, 2)
+        result["cold_whole_batch_hbm_frac"] = round((job.encoded + job.decoded) / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
     if solo and not args.no_breakdown:
         # diagnostic, outside the timed region: the same batch with one launch per
         # (level, operation), which attributes device time to operations

@@ -65,6 +65,11 @@ typedef struct nbl_options {
                                       * are gathered from memory inside the fused launch); 0 = the library's
                                       * default (4096).  Read when struct_size >= 20.  No counterpart in the
                                       * reference. */
+  uint32_t plan_threads;             /* host threads that walk the chunk headers of one nbl_plan_batch call; 0 = the
+                                      * library's choice (up to 16, one per 128 chunks; NBL_PLAN_THREADS in the
+                                      * environment overrides it), 1 = the calling thread only.  The plan does not
+                                      * depend on it.  Read when struct_size >= 24.  The reference builds its
+                                      * Encoding objects one stream at a time (velox/VeloxReader.cpp:330-351). */
 } nbl_options;
 
 /* By default every cascade level of the batch is ONE kernel launch whose tiles
@@ -244,6 +249,15 @@ typedef struct nbl_launch_info {
 } nbl_launch_info;
 
 nbl_status nbl_plan_get_launch(const nbl_plan* plan, uint32_t launch, nbl_launch_info* info);
+
+/*
+ * A 64-bit hash of everything a decode of the plan reads or reports: the
+ * descriptor tables as they are uploaded, the launch list, every chunk layout
+ * and the buffer sizes.  Two plans of the same bytes with equal fingerprints
+ * decode alike; how a plan was made (nbl_options.plan_threads) must not show
+ * in it.  No counterpart in the reference; for tests.
+ */
+nbl_status nbl_plan_fingerprint(const nbl_plan* plan, uint64_t* fingerprint);
 
 /*
  * Per-launch timing with HIP events recorded on the decode stream (no

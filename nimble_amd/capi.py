@@ -25,13 +25,14 @@ EXPORTED_SYMBOLS = (
     "nbl_split_stream", "nbl_plan_upload", "nbl_decode_batch_device", "nbl_decode_status",
     "nbl_plan_get_launch", "nbl_last_error", "nbl_build_arch", "nbl_build_source_id",
     "nbl_profile_create", "nbl_profile_free", "nbl_decode_batch_profiled", "nbl_profile_collect",
-    "nbl_split_stream_ex", "nbl_uncompressed_size", "nbl_uncompress", "nbl_chunk_inflated_size", "nbl_chunk_inflate",
+    "nbl_plan_fingerprint", "nbl_split_stream_ex", "nbl_uncompressed_size", "nbl_uncompress", "nbl_chunk_inflated_size", "nbl_chunk_inflate",
 )
 
 
 class NblOptions(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("use_varint_row_count", C.c_uint32), ("flags", C.c_uint32),
-                ("wave_scatter_min_tiles", C.c_uint32), ("lds_dictionary_min_tiles", C.c_uint32)]
+                ("wave_scatter_min_tiles", C.c_uint32), ("lds_dictionary_min_tiles", C.c_uint32),
+                ("plan_threads", C.c_uint32)]
 
 
 PLAN_PER_KERNEL_LAUNCHES = 1
@@ -130,6 +131,8 @@ def lib():
         L.nbl_decode_status.argtypes = [vp, vp, vp]
         L.nbl_plan_get_launch.restype = C.c_int
         L.nbl_plan_get_launch.argtypes = [vp, u32, C.POINTER(NblLaunchInfo)]
+        L.nbl_plan_fingerprint.restype = C.c_int
+        L.nbl_plan_fingerprint.argtypes = [vp, C.POINTER(u64)]
         L.nbl_profile_create.restype = C.c_int
         L.nbl_profile_create.argtypes = [vp, u32, C.POINTER(vp)]
         L.nbl_profile_free.restype = None

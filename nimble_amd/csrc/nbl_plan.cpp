@@ -11,12 +11,17 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
+#include <new>
 #include <string>
+#include <system_error>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -109,6 +114,20 @@ struct PNode {
   int ready = 0;             // level after which `ref` is valid
 };
 
+// What of a descriptor / a chunk layout is an offset into a region whose base
+// is only known once the batch is put together (per-thread plans are merged by
+// adding the bases): everything else in them is position independent.
+enum : uint8_t {
+  DM_AUX_WORK = 1,   // aux_off is an offset into work (run ends)
+  DM_AUX_OUT = 2,    // aux_off is an offset into out (null bitmap)
+  DM_PARTS = 4,      // part_base
+  DM_TOTALS = 8,     // total_idx
+  DM_PARTS2 = 16,    // part_base2
+  DM_TOTALS2 = 32,   // total_idx2
+  DM_LOOK = 64,      // look_base
+};
+enum : uint8_t { LM_NULLS = 1, LM_STRING = 2, LM_DICT_ALPHABET = 4, LM_DICT_INDICES = 8 };
+
 constexpr size_t kDenseSparseMaxChunks = 512;
 // Positions a SparseBool column of up to kWholeTileRows rows may list and still be
 // built by one workgroup: two rounds of loads in a small batch, sixteen where
@@ -117,9 +136,24 @@ constexpr uint32_t kWholeMaxPositions = 4096, kWholeMaxPositionsBatch = 32768;
 // Rank-scatter tiles of one level (16 KiB of output each) from which the one-wave
 // kernel gets its own launch; a launch of one element size needs an eighth of that.
 constexpr uint64_t kWaveLaunchMinTiles = 32768;
+// Host threads that walk the chunk headers of one batch, and the chunks a thread
+// must have for it to be started (a thread costs tens of microseconds, a chunk one to two).
+constexpr uint32_t kMaxPlanThreads = 16, kChunksPerPlanThread = 128;
 // Tiles (16 KiB of output each) of 2,049 .. 4,096-entry dictionaries of one level
 // from which the LDS-alphabet kernel gets its launch.
 constexpr uint64_t kLdsDictMinTiles = 4096;
+
+// std::vector that leaves the elements resize() adds uninitialised (plain data
+// only): the big tables of a plan are sized once and then filled, by several
+// threads when the batch is large, and zeroing megabytes first is time on one.
+template <class T>
+struct NoInit : std::allocator<T> {
+  template <class U> struct rebind { using other = NoInit<U>; };
+  template <class U> void construct(U* p) noexcept { ::new (static_cast<void*>(p)) U; }
+  template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+template <class T>
+using RawVec = std::vector<T, NoInit<T>>;
 
 struct Step {
   int level;
@@ -129,9 +163,9 @@ struct Step {
   uint32_t n_tiles;
   int chunk;      // >= 0 when this step writes the final values of that chunk
   int owner;      // chunk the step belongs to
-  uint32_t tile_begin = 0;  // first tile of the node this step covers (steps can be split)
-  uint64_t alg = 0;         // algorithmic bytes credited to this step (set by finish())
-  bool filler = false;      // a free step placed in a level to fill it: its tiles go after the level's own
+  uint32_t tile_begin;  // first tile of the node this step covers (steps can be split)
+  uint64_t alg;         // algorithmic bytes credited to this step (set by finish())
+  bool filler;          // a free step placed in a level to fill it: its tiles go after the level's own
 };
 
 struct Launch {
@@ -153,18 +187,19 @@ struct nbl_plan {
   const uint8_t* base = nullptr;
   bool varint_rows = false;
   uint64_t span = 0;
-  std::vector<PNode> nodes;
-  std::vector<int> roots;
+  std::vector<PNode> nodes;               // the cascade tree of the chunk being planned
+  uint32_t n_nodes = 0;                   // encodings of all chunks planned so far
   std::vector<nbl_chunk_layout> layouts;
-  std::vector<NodeDesc> dnodes;
-  std::vector<uint8_t> aux_in_work;       // per dnode: aux_off is an offset into work (run ends)
+  RawVec<NodeDesc> dnodes;
+  RawVec<uint8_t> dn_mask;           // per dnode: DM_* (which fields are offsets to rebase)
+  std::vector<uint8_t> layout_mask;       // per chunk: LM_* (which optional layout offsets are set)
   std::vector<uint32_t> chunk_copies;     // dnodes of the string copies of the chunk being planned
-  std::vector<int> chunk_final_step;      // per chunk: index into steps (before sorting) or -1
+  size_t batch_chunks = 0;                // chunks of the whole batch (a per-thread plan holds a range of them)
   std::vector<uint64_t> chunk_alg;        // per chunk: encoded + decoded bytes
-  std::vector<Step> steps;
+  RawVec<Step> steps;
   std::vector<Launch> launches;
-  std::vector<TileRef> tiles;
-  std::vector<uint32_t> tile_aux;         // parallel to tiles (KArgs::tile_aux)
+  RawVec<TileRef> tiles;
+  RawVec<uint32_t> tile_aux;         // parallel to tiles (KArgs::tile_aux)
   bool keep_dictionary = false;  // also emit alphabet + indices of dictionary chunks
   bool fused = true;          // one launch per cascade level (default) or one per (level, kernel, element size)
   bool wave_scatter = true;   // sparse rank scatters on the one-wave kernel (default) or every one on the four-wave tile
@@ -172,7 +207,6 @@ struct nbl_plan {
   uint64_t lds_dict_min_tiles = kLdsDictMinTiles;  // tiles of such dictionaries in one level that make a launch of that kernel
   uint64_t wave_min_tiles = kWaveLaunchMinTiles;  // tiles of one level and element size that make a one-wave launch
   int cur_chunk = -1;         // chunk being planned
-  std::vector<uint8_t> blob;  // NodeDesc[] | TileRef[] image uploaded to work
   uint64_t tiles_off = 0, aux_off = 0;
   uint64_t ctrl_off = 0, ctrl_bytes = 0;   // status word + per-node totals (zeroed by the upload)
   uint64_t parts_off = 0;
@@ -196,9 +230,9 @@ struct nbl_plan {
   // ---- layout / scheduling ----------------------------------------------
   uint64_t alloc_work(uint64_t bytes) { uint64_t o = cur_work; cur_work = align_up(cur_work + bytes, kAlign); return o; }
   uint64_t alloc_out(uint64_t bytes) { uint64_t o = cur_out; cur_out = align_up(cur_out + bytes, kAlign); return o; }
-  uint32_t add_dnode(const NodeDesc& d, bool aux_work = false) {
+  uint32_t add_dnode(const NodeDesc& d, uint8_t mask = 0) {
     dnodes.push_back(d);
-    aux_in_work.push_back(aux_work ? 1 : 0);
+    dn_mask.push_back(mask);
     return (uint32_t)dnodes.size() - 1;
   }
   void add_step(int level, uint32_t kernel, uint32_t es, uint32_t dnode, uint32_t n_tiles) {
@@ -210,12 +244,17 @@ struct nbl_plan {
   // word, ticket counter, spare), `chain_tiles` look-back words for a chained
   // scan over that many tiles, and -- for the rank scatters, whose tiles read
   // their share from a table -- `rank_parts` scanned partials (+ the total).
-  void alloc_scan(NodeDesc& d, uint32_t n_tiles, uint32_t chain_tiles, bool rank_parts) {
+  // Returns the DM_* bits of the fields it set (for add_dnode).
+  uint8_t alloc_scan(NodeDesc& d, uint32_t n_tiles, uint32_t chain_tiles, bool rank_parts) {
     d.n_parts = n_tiles;
     if (rank_parts) { d.part_base = n_parts; n_parts += n_tiles + 1; }
     d.total_idx = n_totals; n_totals += 4;
     d.look_base = n_look; n_look += chain_tiles > 1 ? chain_tiles : 0;
+    return (uint8_t)(DM_TOTALS | DM_LOOK | (rank_parts ? DM_PARTS : 0));
   }
+  struct MergeBase { size_t dnode, step, chunk; uint64_t out, work; uint32_t parts, totals, look; };
+  MergeBase reserve_behind(const nbl_plan& sub, size_t chunk_base);
+  void copy_from(const nbl_plan& sub, const MergeBase& b);
   uint64_t string_copy(int level, uint64_t arena_off, uint64_t bytes);
   uint64_t column_to_out(const ColRef& src, uint32_t rows, uint32_t es, int level);
   void keep_dictionary_of(int dict_node, bool with_indices);
@@ -555,6 +594,7 @@ void nbl_plan::keep_dictionary_of(int dict_node, bool with_indices) {
   L.has_dictionary = 1;
   L.dict_size = alpha.rows;
   L.dict_alphabet_offset = column_to_out(alpha.ref, alpha.rows, dn.es, alpha.ready);
+  layout_mask[(size_t)dn.chunk] |= LM_DICT_ALPHABET | (with_indices ? LM_DICT_INDICES : 0);
   if (with_indices) {
     L.dict_indices_rows = dn.rows;
     L.dict_indices_offset = column_to_out(ind.ref, dn.rows, 4, ind.ready);
@@ -627,8 +667,8 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
         d.c0 = C(0).ref; d.c0.rows = std::min(d.c0.rows, C(0).rows);
         d.rows = rows; d.aux = rel; d.aux2 = nn.payload_bytes;
         const uint32_t nt = div_up32(rows, kScanTile);
-        alloc_scan(d, nt, nt, false);  // the offsets: a chained scan over the view tiles, one step
-        const uint32_t dn = add_dnode(d);
+        const uint8_t sm = alloc_scan(d, nt, nt, false);  // the offsets: a chained scan over the view tiles, one step
+        const uint32_t dn = add_dnode(d, sm);
         add_step(lvl, K_STRING_VIEWS, 8, dn, nt);
         nn.ref = d.self; nn.ready = lvl + 1;
       } else if (nn.is_bool) {
@@ -657,8 +697,8 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       d.c0.kind = COL_RAW; d.c0.off = nn.payload_off; d.c0.base = nn.value; d.c0.rows = rows; d.c0.es = (uint8_t)es;
       d.rows = rows; d.aux2 = nn.payload_bytes;
       const uint32_t nt = div_up32(nn.payload_bytes, kVarintTile);
-      alloc_scan(d, nt, nt, false);  // the ordinals: a chained scan over the decode tiles, one step
-      const uint32_t dn = add_dnode(d);
+      const uint8_t sm = alloc_scan(d, nt, nt, false);  // the ordinals: a chained scan over the decode tiles, one step
+      const uint32_t dn = add_dnode(d, sm);
       add_step(lvl, K_VARINT_DECODE, es, dn, nt);
       nn.ref = d.self; nn.ready = lvl + 1;
       break;
@@ -682,7 +722,7 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       const uint32_t R = C(0).rows;
       d.c0.rows = R;
       const uint32_t nt = div_up32(R, kScanTile);
-      alloc_scan(d, nt, nt, false);  // the run ends: a chained scan over the tiles of runs, one step
+      const uint8_t sm = alloc_scan(d, nt, nt, false);  // the run ends: a chained scan over the tiles of runs, one step
       // run ends (R entries, 16-byte rounded) followed by first_run[] (one entry per output tile)
       const uint32_t out_tile_rows = nn.is_bool ? kBitTileRows : tile_rows;
       d.aux2 = out_tile_rows;
@@ -699,7 +739,7 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
         if (!nn.fused_runs) d.self = mat_ref(es);
         d.c1 = C(1).ref;
       }
-      const uint32_t dn = add_dnode(d, /*aux_work=*/true);
+      const uint32_t dn = add_dnode(d, sm | DM_AUX_WORK);
       int at = lvl;
       add_step(at++, K_RLE_ENDS, 4, dn, nt);
       if (nn.fused_runs) {
@@ -728,13 +768,13 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       // workgroup slots and wait for the slowest tile.  A batch of thousands of
       // columns is bound by the fixed cost per tile instead (measured: +16%
       // on the bitmap level of a 5,000-column stripe with the small tiles).
-      const bool dense = (uint64_t)C(0).rows * 32 > rows && layouts.size() <= kDenseSparseMaxChunks;
+      const bool dense = (uint64_t)C(0).rows * 32 > rows && batch_chunks <= kDenseSparseMaxChunks;
       // A column of up to 131072 rows is one tile when its positions take few
       // rounds of loads (16 rounds of 2048 in a batch that fills the chip anyway,
       // 2 otherwise): no search for the tile's range of positions, and a parent
       // selecting by the bitmap gets its rank partials already scanned.
       const bool whole = rows > 0 && rows <= kWholeTileRows &&
-                         C(0).rows <= (layouts.size() > kDenseSparseMaxChunks ? kWholeMaxPositionsBatch : kWholeMaxPositions);
+                         C(0).rows <= (batch_chunks > kDenseSparseMaxChunks ? kWholeMaxPositionsBatch : kWholeMaxPositions);
       if (whole) d.flags |= NF_WHOLE_NODE;
       else if (dense) d.flags |= NF_SPARSE_DENSE;
       const uint32_t dn = add_dnode(d);
@@ -835,8 +875,12 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       const bool counted = selc.enc == ET_SPARSEBOOL && selc.sparse_dn >= 0 && selc.rows == rows;
       const bool whole = !counted && rows > 0 && rows <= kWholeTileRows;  // one workgroup counts the node alone
       const uint32_t popc_tiles = whole ? 1u : div_up32(rows, kPopcTileRows);
-      alloc_scan(d, nt, counted ? 0u : popc_tiles, true);
+      uint8_t sm = alloc_scan(d, nt, counted ? 0u : popc_tiles, true);
+      if (d.flags & NF_WRITE_NULLS) sm |= DM_AUX_OUT;
+      if (d.flags & NF_NESTED_SELECT) sm |= DM_PARTS2 | DM_TOTALS2;
+      if (d.flags & NF_RLE_VALUES) sm |= DM_TOTALS2;
       if (counted) {
+        dn_mask[(size_t)selc.sparse_dn] |= DM_PARTS | DM_TOTALS;
         NodeDesc& sd = dnodes[(size_t)selc.sparse_dn];
         sd.flags |= NF_EMIT_PARTS | (nullable ? 0u : (uint32_t)NF_INVERT_SEL);
         sd.part_base = d.part_base;
@@ -850,7 +894,7 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       const int fin = std::max(lvl, counted ? sel_lvl : sel_lvl + 1);
       if (nn.fused_select) {
         // the parent scatters for this node: it only counts its ranks
-        const uint32_t dn = add_dnode(d);
+        const uint32_t dn = add_dnode(d, sm);
         if (!counted) add_step(sel_lvl, K_REDUCE_POPC, 0, dn, popc_tiles);
         nn.sel_ref = d.sel;
         nn.sel_part_base = d.part_base;
@@ -861,7 +905,7 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
         break;
       }
       d.self = nn.is_bool ? bits_ref() : mat_ref(es);
-      const uint32_t dn = add_dnode(d);
+      const uint32_t dn = add_dnode(d, sm);
       if (!counted) add_step(sel_lvl, K_REDUCE_POPC, 0, dn, popc_tiles);  // each tile emits the partials of kPopcTileRows / trows consumer tiles
       // Tiles that stage few values (a sparse selection, or a nested one whose
       // staged values are the few "other" ones) go to the one-wave kernel: on the
@@ -941,9 +985,9 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
 
 void nbl_plan::plan_chunk(uint32_t c, uint64_t off, uint64_t size) {
   chunk_copies.clear();
+  nodes.clear();  // a tree is needed only while its chunk is placed
   cur_chunk = (int)c;
   const int root = parse(off, size, (int)c, 0);
-  roots.push_back(root);
   const PNode r = nodes[root];
   nbl_chunk_layout& L = layouts[c];
   memset(&L, 0, sizeof L);
@@ -953,9 +997,11 @@ void nbl_plan::plan_chunk(uint32_t c, uint64_t off, uint64_t size) {
   L.non_null_rows = L.nullable ? nodes[r.child[0]].rows : r.rows;
   L.values_bytes = (uint64_t)r.rows * L.elem_bytes;
   L.values_offset = alloc_out(L.values_bytes);
+  layout_mask[c] = 0;
   if (L.nullable) {
     L.nulls_bytes = ((uint64_t)r.rows + 63) / 64 * 8;
     L.nulls_offset = alloc_out(L.nulls_bytes);
+    layout_mask[c] |= LM_NULLS;
   }
   ColRef dst{};
   dst.kind = COL_MAT_OUT; dst.off = L.values_offset; dst.rows = r.rows; dst.es = L.elem_bytes;
@@ -968,17 +1014,79 @@ void nbl_plan::plan_chunk(uint32_t c, uint64_t off, uint64_t size) {
     for (size_t i = first_step; i < steps.size(); ++i)
       if (steps[i].kernel != K_COPY_BYTES && (best < 0 || steps[i].level >= steps[(size_t)best].level)) best = (int)i;
     if (best >= 0) steps[(size_t)best].chunk = (int)c;
-    chunk_final_step.push_back(best);
   }
   if (r.is_string) {
     L.string_bytes = cur_str;
     L.string_offset = alloc_out(cur_str);
+    layout_mask[c] |= LM_STRING;
     for (uint32_t dn : chunk_copies) dnodes[dn].self.off += L.string_offset;
   }
   encoded_bytes += size;
   decoded_bytes += L.values_bytes + L.nulls_bytes;
   chunk_alg.push_back(size + (decoded_bytes - decoded_before));
   total_rows += r.rows;
+  n_nodes += (uint32_t)nodes.size();
+}
+
+// Putting per-thread plans together: each was made over a range of chunks with
+// cursors that started at zero, so its indices and offsets move by what the
+// plans in front of it hold -- exactly where a single walk over all chunks
+// would have put them (every allocation is a multiple of kAlign long).
+// reserve_behind() gives a plan its place (called in chunk order, by one
+// thread), copy_from() moves its tables there (ranges do not overlap: one
+// thread per plan).
+nbl_plan::MergeBase nbl_plan::reserve_behind(const nbl_plan& sub, size_t chunk_base) {
+  MergeBase b{dnodes.size(), steps.size(), chunk_base, cur_out, cur_work, n_parts, n_totals, n_look};
+  dnodes.resize(dnodes.size() + sub.dnodes.size());
+  dn_mask.resize(dnodes.size());
+  steps.resize(steps.size() + sub.steps.size());
+  chunk_alg.resize(chunk_base + sub.chunk_alg.size());
+  cur_out += sub.cur_out; cur_work += sub.cur_work;
+  n_parts += sub.n_parts; n_totals += sub.n_totals; n_look += sub.n_look;
+  n_nodes += sub.n_nodes;
+  encoded_bytes += sub.encoded_bytes; decoded_bytes += sub.decoded_bytes; total_rows += sub.total_rows;
+  max_depth = std::max(max_depth, sub.max_depth);
+  return b;
+}
+
+void nbl_plan::copy_from(const nbl_plan& sub, const MergeBase& b) {
+  for (size_t i = 0; i < sub.dnodes.size(); ++i) {
+    NodeDesc d = sub.dnodes[i];
+    const uint8_t m = sub.dn_mask[i];
+    ColRef* refs[4] = {&d.self, &d.c0, &d.c1, &d.sel};
+    for (ColRef* r : refs) {
+      if (r->kind == COL_MAT_OUT) r->off += b.out;
+      else if (r->kind == COL_MAT_WORK || r->kind == COL_BITS_WORK) r->off += b.work;
+    }
+    if (m & DM_AUX_WORK) d.aux_off += b.work;
+    if (m & DM_AUX_OUT) d.aux_off += b.out;
+    if (m & DM_PARTS) d.part_base += b.parts;
+    if (m & DM_TOTALS) d.total_idx += b.totals;
+    if (m & DM_LOOK) d.look_base += b.look;
+    if (m & DM_PARTS2) d.part_base2 += b.parts;
+    if (m & DM_TOTALS2) d.total_idx2 += b.totals;
+    dnodes[b.dnode + i] = d;
+    dn_mask[b.dnode + i] = m;
+  }
+  for (size_t i = 0; i < sub.steps.size(); ++i) {
+    Step st = sub.steps[i];
+    st.dnode += (uint32_t)b.dnode;
+    if (st.chunk >= 0) st.chunk += (int)b.chunk;
+    if (st.owner >= 0) st.owner += (int)b.chunk;
+    steps[b.step + i] = st;
+  }
+  for (size_t i = 0; i < sub.layouts.size(); ++i) {
+    nbl_chunk_layout L = sub.layouts[i];
+    const uint8_t m = sub.layout_mask[i];
+    L.values_offset += b.out;
+    if (m & LM_NULLS) L.nulls_offset += b.out;
+    if (m & LM_STRING) L.string_offset += b.out;
+    if (m & LM_DICT_ALPHABET) L.dict_alphabet_offset += b.out;
+    if (m & LM_DICT_INDICES) L.dict_indices_offset += b.out;
+    layouts[b.chunk + i] = L;
+    layout_mask[b.chunk + i] = m;
+    chunk_alg[b.chunk + i] = sub.chunk_alg[i];
+  }
 }
 
 // A step is free when nothing on the device depends on it and it depends on
@@ -1065,7 +1173,20 @@ void nbl_plan::spread_free_steps(int last_level) {
 // with latency-bound ones (run expansion, rank scatter).
 // Launches: fused (default) = one launch per level, tiles sorted by operation;
 // otherwise one launch per (level, kernel, element size).
+// NBL_PLAN_TIMING=1 in the environment: nbl_plan_batch prints the milliseconds of its phases (tuning aid).
+static const bool g_plan_timing = getenv("NBL_PLAN_TIMING") != nullptr;
+struct PhaseClock {
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void mark(const char* what) {
+    if (!g_plan_timing) return;
+    const auto n = std::chrono::steady_clock::now();
+    fprintf(stderr, "[nbl_plan] %-12s %7.3f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+    t = n;
+  }
+};
+
 void nbl_plan::finish() {
+  PhaseClock clock;
   int last_level = 0;
   std::vector<int> chunk_last(layouts.size(), 0);
   for (const Step& st : steps) {
@@ -1117,6 +1238,7 @@ void nbl_plan::finish() {
       }
   }
   if (fused && last_level > 0) spread_free_steps(last_level);
+  clock.mark("levels");
   {  // stable counting sort by (level, filler, kernel, element size): wide tables have ~10 steps per column
     // within a level: the level's own fusable steps, the fillers, then the steps that launch on their own
     auto key = [](const Step& st) {
@@ -1126,7 +1248,7 @@ void nbl_plan::finish() {
     std::vector<uint32_t> first((size_t)(last_level + 1) * 3 * K_COUNT * 4 + 1, 0);
     for (const Step& st : steps) ++first[key(st) + 1];
     for (size_t i = 1; i < first.size(); ++i) first[i] += first[i - 1];
-    std::vector<Step> sorted(steps.size());
+    RawVec<Step> sorted(steps.size());
     for (const Step& st : steps) sorted[first[key(st)]++] = st;
     steps.swap(sorted);
     // Rank scatters of one (level, element size) are grouped by what their tiles
@@ -1145,35 +1267,45 @@ void nbl_plan::finish() {
         return (d.flags & (NF_NESTED_SELECT | NF_RLE_VALUES | NF_DICT_VALUES | NF_INVERT_SEL)) << 16 | (uint32_t)d.c1.kind << 12 |
                (uint32_t)(d.c1.width > 25) << 11 | (uint32_t)d.sel.kind << 4 | density;
       };
+      // a group is ordered by a key computed once per step (the descriptors are
+      // megabytes apart: a comparator that reads them misses the cache every time)
+      std::vector<std::pair<uint64_t, uint32_t>> order;
+      std::vector<Step> group;
+      auto reorder = [&](size_t i, size_t j, auto&& key_of) {
+        order.clear();
+        for (size_t k = i; k < j; ++k) order.emplace_back(((uint64_t)key_of(steps[k]) << 32) | (uint32_t)(k - i), (uint32_t)k);
+        std::sort(order.begin(), order.end());  // the position in the low half keeps equal keys in chunk order
+        group.assign(steps.begin() + (ptrdiff_t)i, steps.begin() + (ptrdiff_t)j);
+        for (size_t k = 0; k < order.size(); ++k) steps[i + k] = group[order[k].second - i];
+      };
       for (size_t i = 0; i < steps.size();) {
         size_t j = i;
         while (j < steps.size() && key(steps[j]) == key(steps[i])) ++j;
         if ((steps[i].kernel == K_SELECT_SCATTER || steps[i].kernel == K_SELECT_SCATTER_WAVE) && j - i >= kGroupVariantsFrom)
-          std::stable_sort(steps.begin() + (ptrdiff_t)i, steps.begin() + (ptrdiff_t)j,
-                           [&](const Step& x, const Step& y) { return variant(x) < variant(y); });
+          reorder(i, j, variant);
         // Bitmap tiles of SparseBool columns cost in proportion to the positions
         // they read (a column of 20,000 takes ten rounds of loads, one of 1,000
         // a single one): the long ones go first, so that the level ends with
         // short tiles filling the gaps instead of a few long ones running alone.
         if (steps[i].kernel == K_SPARSE_BITS && j - i >= kGroupVariantsFrom)
-          std::stable_sort(steps.begin() + (ptrdiff_t)i, steps.begin() + (ptrdiff_t)j, [&](const Step& x, const Step& y) {
-            return dnodes[x.dnode].c0.rows / x.n_tiles > dnodes[y.dnode].c0.rows / y.n_tiles;
-          });
+          reorder(i, j, [&](const Step& x) { return ~(dnodes[x.dnode].c0.rows / x.n_tiles); });
         i = j;
       }
     }
   }
+  clock.mark("sort");
   {
     size_t n_tiles_total = 0;
     for (const Step& st : steps) n_tiles_total += st.n_tiles;
-    tiles.reserve(n_tiles_total);
-    tile_aux.reserve(n_tiles_total);
+    tiles.resize(n_tiles_total);
+    tile_aux.resize(n_tiles_total);
   }
+  size_t n_filled = 0;  // entries of the two tables written so far
   for (size_t i = 0; i < steps.size();) {
     size_t j = i;
-    Launch L{steps[i].kernel, steps[i].es, (uint32_t)tiles.size(), 0, steps[i].level, 0, std::string()};
+    Launch L{steps[i].kernel, steps[i].es, (uint32_t)n_filled, 0, steps[i].level, 0, std::string()};
     const bool fuse = fused && kernel_is_fusable(steps[i].kernel);
-    size_t first_filler = tiles.size();  // where the level's filler tiles start in the table
+    size_t first_filler = n_filled;  // where the level's filler tiles start in the table
     bool fillers = false;
     while (j < steps.size() && steps[j].level == steps[i].level &&
            (fuse ? kernel_is_fusable(steps[j].kernel) : (steps[j].kernel == steps[i].kernel && steps[j].es == steps[i].es))) {
@@ -1182,25 +1314,30 @@ void nbl_plan::finish() {
       const bool scatter = steps[j].kernel == K_SELECT_SCATTER || steps[j].kernel == K_SELECT_SCATTER_WAVE ||
                            (lds_dict && (dnodes[steps[j].dnode].flags & NF_DICT_VALUES));
       const uint32_t aux_base = scatter ? dnodes[steps[j].dnode].part_base : 0u;
-      if (steps[j].filler && !fillers) { fillers = true; first_filler = tiles.size(); }
-      for (uint32_t t = 0; t < steps[j].n_tiles; ++t) {
-        tiles.push_back(TileRef{steps[j].dnode, op | (steps[j].tile_begin + t)});
-        tile_aux.push_back(scatter ? aux_base + (steps[j].tile_begin + t) * (lds_dict ? kDictLdsTiles : 1u) : 0u);
+      if (steps[j].filler && !fillers) { fillers = true; first_filler = n_filled; }
+      {
+        TileRef* tr = tiles.data() + n_filled;
+        uint32_t* ax = tile_aux.data() + n_filled;
+        const uint32_t dn = steps[j].dnode, t0 = steps[j].tile_begin, nt = steps[j].n_tiles;
+        const uint32_t per = lds_dict ? kDictLdsTiles : 1u;
+        for (uint32_t t = 0; t < nt; ++t) tr[t] = TileRef{dn, op | (t0 + t)};
+        for (uint32_t t = 0; t < nt; ++t) ax[t] = scatter ? aux_base + (t0 + t) * per : 0u;
+        n_filled += nt;
       }
       L.alg_bytes += steps[j].alg;
       ++j;
     }
-    L.n_tiles = (uint32_t)tiles.size() - L.tile_begin;
+    L.n_tiles = (uint32_t)n_filled - L.tile_begin;
     if (fuse && fillers && first_filler > L.tile_begin) {
       // The level's own tiles (chained scans, bitmap builds: each a chain of trips
       // to memory) hold a workgroup slot for several times as long as a filler
       // tile moves its 16 KiB.  Launched first they fill every slot of the chip
       // and the fillers' bandwidth waits for them; dealt out among the fillers
       // over the first three quarters of the launch, both run side by side.
-      const size_t n_own = first_filler - L.tile_begin, n_fill = tiles.size() - first_filler;
+      const size_t n_own = first_filler - L.tile_begin, n_fill = n_filled - first_filler;
       const size_t span = std::max(n_own, (n_own + n_fill) * 3 / 4);  // table slots the own tiles are spread over
-      std::vector<TileRef> merged;
-      std::vector<uint32_t> merged_aux;
+      RawVec<TileRef> merged;
+      RawVec<uint32_t> merged_aux;
       merged.reserve(n_own + n_fill);
       merged_aux.reserve(n_own + n_fill);
       size_t o = 0, f = 0;
@@ -1224,6 +1361,7 @@ void nbl_plan::finish() {
     launches.push_back(L);
     i = j;
   }
+  clock.mark("tile table");
   // work = [NodeDesc[] | TileRef[] | tile_aux[]] [ctrl] [parts] [intermediates...]
   const uint64_t nd_bytes = align_up(dnodes.size() * sizeof(NodeDesc), kAlign);
   const uint64_t tl_bytes = align_up(tiles.size() * sizeof(TileRef), kAlign);
@@ -1243,13 +1381,10 @@ void nbl_plan::finish() {
       if (r->kind == COL_MAT_WORK || r->kind == COL_BITS_WORK) r->off += scratch_base;
   }
   for (size_t i = 0; i < dnodes.size(); ++i)
-    if (aux_in_work[i]) dnodes[i].aux_off += scratch_base;  // run-end arrays
+    if (dn_mask[i] & DM_AUX_WORK) dnodes[i].aux_off += scratch_base;  // run-end arrays
   work_bytes = scratch_base + cur_work + kAlign;
   out_bytes = cur_out + kAlign;  // slack: staged 16-byte loads may run a few bytes past a column
-  blob.assign(desc_bytes, 0);
-  if (!dnodes.empty()) memcpy(blob.data(), dnodes.data(), dnodes.size() * sizeof(NodeDesc));
-  if (!tiles.empty()) memcpy(blob.data() + tiles_off, tiles.data(), tiles.size() * sizeof(TileRef));
-  if (!tile_aux.empty()) memcpy(blob.data() + aux_off, tile_aux.data(), tile_aux.size() * sizeof(uint32_t));
+  clock.mark("layout");
 }
 
 // =============================== C ABI =====================================
@@ -1315,23 +1450,94 @@ nbl_status nbl_plan_batch(const uint8_t* base, const uint64_t* offsets, const ui
     if (options && options->struct_size >= 16 && options->wave_scatter_min_tiles) p->wave_min_tiles = options->wave_scatter_min_tiles;
     if (options && options->struct_size >= 20 && options->lds_dictionary_min_tiles) p->lds_dict_min_tiles = options->lds_dictionary_min_tiles;
     p->layouts.resize(n_chunks);
+    p->layout_mask.resize(n_chunks);
+    p->batch_chunks = n_chunks;
     for (uint32_t c = 0; c < n_chunks; ++c) {
       if (offsets[c] + sizes[c] < offsets[c]) fail(NBL_ERR_ARGUMENT, "chunk %u: offset + size overflows", c);
       p->span = std::max(p->span, offsets[c] + sizes[c]);
     }
-    p->nodes.reserve((size_t)n_chunks * 8);
-    p->dnodes.reserve((size_t)n_chunks * 4);
-    p->aux_in_work.reserve((size_t)n_chunks * 4);
-    p->steps.reserve((size_t)n_chunks * 8);
-    p->roots.reserve(n_chunks);
-    p->chunk_alg.reserve(n_chunks);
-    p->chunk_final_step.reserve(n_chunks);
-    for (uint32_t c = 0; c < n_chunks; ++c) {
-      // the headers of a wide table are spread over hundreds of megabytes: have
-      // the prefix of a later chunk on its way while this one is walked
-      if (c + 8 < n_chunks && sizes[c + 8]) __builtin_prefetch(base + offsets[c + 8]);
-      p->plan_chunk(c, offsets[c], sizes[c]);
+    auto reserve_for = [](nbl_plan& q, size_t chunks) {
+      q.nodes.reserve(64);
+      q.dnodes.reserve(chunks * 4);
+      q.dn_mask.reserve(chunks * 4);
+      q.steps.reserve(chunks * 8);
+      q.chunk_alg.reserve(chunks);
+    };
+    // The chunks are independent (so are their headers, spread over the whole
+    // stripe: the walk waits on memory), so a large batch is walked by several
+    // threads, each over a range of chunks with cursors of its own, and the
+    // per-thread plans are put together in chunk order.
+    uint32_t threads = options && options->struct_size >= 24 ? options->plan_threads : 0;
+    if (threads == 0) {
+      if (const char* e = getenv("NBL_PLAN_THREADS")) threads = (uint32_t)atoi(e);
+      if (threads == 0) threads = std::min<uint32_t>(std::max(1u, std::thread::hardware_concurrency()), kMaxPlanThreads);
+      threads = std::min<uint32_t>(threads, n_chunks / kChunksPerPlanThread);  // small batches: not worth starting threads for
     }
+    threads = std::max(1u, std::min<uint32_t>(std::min<uint32_t>(threads, 64), std::max(1u, n_chunks)));
+    PhaseClock clock;
+    if (threads <= 1) {
+      reserve_for(*p, n_chunks);
+      for (uint32_t c = 0; c < n_chunks; ++c) {
+        // the headers of a wide table are spread over hundreds of megabytes: have
+        // the prefix of a later chunk on its way while this one is walked
+        if (c + 8 < n_chunks && sizes[c + 8]) __builtin_prefetch(base + offsets[c + 8]);
+        p->plan_chunk(c, offsets[c], sizes[c]);
+      }
+    } else {
+      std::vector<std::unique_ptr<nbl_plan>> subs(threads);
+      std::vector<PlanError> errors(threads, PlanError{NBL_OK, std::string()});
+      std::vector<uint32_t> first(threads + 1);
+      for (uint32_t t = 0; t <= threads; ++t) first[t] = (uint32_t)((uint64_t)n_chunks * t / threads);
+      auto walk = [&](uint32_t t) {
+        try {
+          subs[t].reset(new nbl_plan());
+          nbl_plan& q = *subs[t];
+          q.base = base; q.varint_rows = p->varint_rows; q.fused = p->fused; q.keep_dictionary = p->keep_dictionary;
+          q.wave_scatter = p->wave_scatter; q.lds_dictionary = p->lds_dictionary; q.batch_chunks = n_chunks;
+          const uint32_t c0 = first[t], c1 = first[t + 1];
+          q.layouts.resize(c1 - c0);
+          q.layout_mask.resize(c1 - c0);
+          reserve_for(q, c1 - c0);
+          for (uint32_t c = c0; c < c1; ++c) {
+            if (c + 8 < c1 && sizes[c + 8]) __builtin_prefetch(base + offsets[c + 8]);
+            q.plan_chunk(c - c0, offsets[c], sizes[c]);
+          }
+        } catch (const PlanError& e) {
+          errors[t] = e;
+        } catch (const std::exception& e) {
+          errors[t] = PlanError{NBL_ERR_ARGUMENT, e.what()};
+        }
+      };
+      // runs job(t) for every range: range 0 on this thread, the others on threads of their own
+      auto on_all = [&](auto&& job) {
+        std::vector<std::thread> pool;
+        pool.reserve(threads - 1);
+        uint32_t started = 1;
+        try {
+          for (; started < threads; ++started) pool.emplace_back(job, started);
+        } catch (const std::system_error&) {
+          // no more threads to be had: this one takes the ranges that got none
+        }
+        job(0u);
+        for (uint32_t t = started; t < threads; ++t) job(t);
+        for (std::thread& th : pool) th.join();
+      };
+      on_all(walk);
+      clock.mark("walk");
+      // the error a single walk would have met first: that of the lowest range
+      for (uint32_t t = 0; t < threads; ++t)
+        if (errors[t].status != NBL_OK) throw errors[t];
+      size_t nd = 0, ns = 0;
+      for (const auto& q : subs) { nd += q->dnodes.size(); ns += q->steps.size(); }
+      p->dnodes.reserve(nd); p->dn_mask.reserve(nd); p->steps.reserve(ns);
+      std::vector<nbl_plan::MergeBase> bases(threads);
+      for (uint32_t t = 0; t < threads; ++t) bases[t] = p->reserve_behind(*subs[t], first[t]);
+      on_all([&](uint32_t t) {
+        p->copy_from(*subs[t], bases[t]);
+        subs[t].reset();
+      });
+    }
+    clock.mark(threads <= 1 ? "walk" : "merge");
     p->finish();
     p->base = nullptr;  // the host bytes are not needed after planning
   } catch (const PlanError& e) {
@@ -1353,7 +1559,7 @@ nbl_status nbl_plan_get_info(const nbl_plan* p, nbl_plan_info* info) {
   if (!p || !info) { g_last_error = "null argument"; return NBL_ERR_ARGUMENT; }
   memset(info, 0, sizeof *info);
   info->n_chunks = (uint32_t)p->layouts.size();
-  info->n_nodes = (uint32_t)p->nodes.size();
+  info->n_nodes = p->n_nodes;
   info->n_launches = (uint32_t)p->launches.size();
   info->max_depth = p->max_depth;
   info->arena_bytes = p->span + kArenaSlop;
@@ -1384,6 +1590,30 @@ nbl_status nbl_plan_get_launch(const nbl_plan* p, uint32_t launch, nbl_launch_in
   return NBL_OK;
 }
 
+nbl_status nbl_plan_fingerprint(const nbl_plan* p, uint64_t* fingerprint) {
+  if (!p || !fingerprint) { g_last_error = "null argument"; return NBL_ERR_ARGUMENT; }
+  uint64_t h = 0xcbf29ce484222325ull;  // FNV-1a over 8-byte words (tails byte by byte)
+  auto mix = [&](const void* data, size_t bytes) {
+    const uint8_t* b = static_cast<const uint8_t*>(data);
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) { uint64_t w; memcpy(&w, b + i, 8); h = (h ^ w) * 0x100000001b3ull; }
+    for (; i < bytes; ++i) h = (h ^ b[i]) * 0x100000001b3ull;
+  };
+  mix(p->dnodes.data(), p->dnodes.size() * sizeof(NodeDesc));
+  mix(p->tiles.data(), p->tiles.size() * sizeof(TileRef));
+  mix(p->tile_aux.data(), p->tile_aux.size() * sizeof(uint32_t));
+  for (const nbl_chunk_layout& L : p->layouts) mix(&L, sizeof L);
+  for (const Launch& L : p->launches) {
+    const uint64_t f[6] = {L.kernel, L.es, L.tile_begin, L.n_tiles, (uint64_t)L.level, L.alg_bytes};
+    mix(f, sizeof f);
+  }
+  const uint64_t sizes[12] = {p->span, p->out_bytes, p->work_bytes, p->desc_bytes, p->tiles_off, p->aux_off, p->ctrl_off,
+                              p->ctrl_bytes, p->parts_off, p->look_off, p->n_nodes, p->total_rows};
+  mix(sizes, sizeof sizes);
+  *fingerprint = h;
+  return NBL_OK;
+}
+
 static nbl_status hip_fail(const char* what, hipError_t e) {
   g_last_error = std::string(what) + ": " + hipGetErrorString(e);
   return NBL_ERR_HIP;
@@ -1391,13 +1621,21 @@ static nbl_status hip_fail(const char* what, hipError_t e) {
 
 nbl_status nbl_plan_upload(nbl_plan* p, void* d_work, void* stream) {
   if (!p || !d_work) { g_last_error = "null argument"; return NBL_ERR_ARGUMENT; }
-  if (p->blob.empty()) return NBL_OK;
-  hipError_t e = hipMemcpyAsync(d_work, p->blob.data(), p->blob.size(), hipMemcpyHostToDevice, static_cast<hipStream_t>(stream));
+  // the three descriptor tables go up from where the planner built them (no
+  // image of `work` is assembled on the host); the padding between them is never read
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  uint8_t* work = static_cast<uint8_t*>(d_work);
+  hipError_t e = hipSuccess;
+  if (!p->dnodes.empty()) e = hipMemcpyAsync(work, p->dnodes.data(), p->dnodes.size() * sizeof(NodeDesc), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess && !p->tiles.empty())
+    e = hipMemcpyAsync(work + p->tiles_off, p->tiles.data(), p->tiles.size() * sizeof(TileRef), hipMemcpyHostToDevice, s);
+  if (e == hipSuccess && !p->tile_aux.empty())
+    e = hipMemcpyAsync(work + p->aux_off, p->tile_aux.data(), p->tile_aux.size() * sizeof(uint32_t), hipMemcpyHostToDevice, s);
   if (e != hipSuccess) return hip_fail("hipMemcpyAsync(descriptors)", e);
   // The control words start at zero here and are not touched by the host again
   // until nbl_decode_status: the flag word only gathers bits, and the kernels
   // reset the per-node words they accumulate into, so a decode is launches only.
-  e = hipMemsetAsync(static_cast<uint8_t*>(d_work) + p->ctrl_off, 0, p->ctrl_bytes, static_cast<hipStream_t>(stream));
+  e = hipMemsetAsync(work + p->ctrl_off, 0, p->ctrl_bytes, s);
   if (e != hipSuccess) return hip_fail("hipMemsetAsync(control words)", e);
   return NBL_OK;
 }

@@ -4,6 +4,7 @@ decode, fetch results.  PyTorch is used only for device memory and streams.
 from __future__ import annotations
 
 import ctypes as C
+import time
 from dataclasses import dataclass
 from typing import Optional, Sequence
 
@@ -33,7 +34,7 @@ class Plan:
 
     def __init__(self, buffer, chunks: Sequence[tuple[int, int]], varint_rows: bool = False, per_kernel: bool = False,
                  keep_dictionary: bool = False, four_wave_scatter: bool = False, wave_scatter_min_tiles: int = 0,
-                 no_lds_dictionary: bool = False, lds_dictionary_min_tiles: int = 0):
+                 no_lds_dictionary: bool = False, lds_dictionary_min_tiles: int = 0, plan_threads: int = 0):
         """per_kernel: one launch per (level, operation) instead of one fused
         launch per cascade level -- for profiling, same results.
         four_wave_scatter: no rank scatter on the one-wave kernel -- same results.
@@ -41,7 +42,8 @@ class Plan:
         launched (0: the library's default).
         no_lds_dictionary: every dictionary gathered from memory -- same results.
         lds_dictionary_min_tiles: tiles of a level from which the LDS-alphabet dictionary
-        kernel is launched (0: the library's default)."""
+        kernel is launched (0: the library's default).
+        plan_threads: host threads walking the chunk headers (0: the library's choice, 1: this thread)."""
         self.buffer = capi.as_u8(buffer)
         self.chunks = [(int(o), int(s)) for o, s in chunks]
         n = len(self.chunks)
@@ -55,10 +57,13 @@ class Plan:
                                (capi.PLAN_KEEP_DICTIONARY if keep_dictionary else 0) |
                                (capi.PLAN_FOUR_WAVE_SCATTER if four_wave_scatter else 0) |
                                (capi.PLAN_NO_LDS_DICTIONARY if no_lds_dictionary else 0), int(wave_scatter_min_tiles),
-                               int(lds_dictionary_min_tiles))
+                               int(lds_dictionary_min_tiles), int(plan_threads))
         handle = C.c_void_p()
-        capi.check(capi.lib().nbl_plan_batch(self.buffer.ctypes.data, offs.ctypes.data, sizes.ctypes.data, n,
-                                             C.byref(opts), C.byref(handle)))
+        lib = capi.lib()
+        t0 = time.perf_counter()
+        status = lib.nbl_plan_batch(self.buffer.ctypes.data, offs.ctypes.data, sizes.ctypes.data, n, C.byref(opts), C.byref(handle))
+        self.plan_seconds = time.perf_counter() - t0  # the header walk + scheduling of the whole batch (host only)
+        capi.check(status)
         self._h = handle
         info = capi.NblPlanInfo()
         capi.check(capi.lib().nbl_plan_get_info(self._h, C.byref(info)))
@@ -73,7 +78,7 @@ class Plan:
     def from_encodings(encodings: Sequence[bytes], varint_rows: bool = False, per_kernel: bool = False,
                        keep_dictionary: bool = False, four_wave_scatter: bool = False,
                        wave_scatter_min_tiles: int = 0, no_lds_dictionary: bool = False,
-                       lds_dictionary_min_tiles: int = 0) -> "Plan":
+                       lds_dictionary_min_tiles: int = 0, plan_threads: int = 0) -> "Plan":
         """Concatenates standalone encodings (16-byte aligned starts are NOT
         required; they are packed back to back on purpose)."""
         offs, pos = [], 0
@@ -82,7 +87,13 @@ class Plan:
             pos += len(e)
         buf = np.frombuffer(b"".join(bytes(e) for e in encodings), dtype=np.uint8) if encodings else np.zeros(0, np.uint8)
         return Plan(buf, offs, varint_rows, per_kernel, keep_dictionary, four_wave_scatter, wave_scatter_min_tiles,
-                    no_lds_dictionary, lds_dictionary_min_tiles)
+                    no_lds_dictionary, lds_dictionary_min_tiles, plan_threads)
+
+    def fingerprint(self) -> int:
+        """Hash of the descriptor tables, launch list, layouts and sizes (nbl_plan_fingerprint)."""
+        h = C.c_uint64(0)
+        capi.check(capi.lib().nbl_plan_fingerprint(self._h, C.byref(h)))
+        return int(h.value)
 
     def launches(self):
         """[(kernel, elem_bytes, n_tiles, level, alg_bytes)] in launch order."""
@@ -134,7 +145,10 @@ class BatchDecoder:
         host = torch.from_numpy(self.plan.buffer.copy() if not self.plan.buffer.flags.writeable else self.plan.buffer)
         with torch.cuda.device(self.device):
             self.arena[: host.numel()].copy_(host, non_blocking=False)
+            t0 = time.perf_counter()
             capi.check(capi.lib().nbl_plan_upload(self.plan._h, C.c_void_p(self.work.data_ptr()), self._stream_ptr()))
+            torch.cuda.current_stream(self.device).synchronize() if self.stream is None else self.stream.synchronize()
+            self.upload_seconds = time.perf_counter() - t0  # descriptor tables to the device
         self._uploaded = True
 
     def decode(self):
