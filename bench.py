@@ -402,7 +402,7 @@ def roofline_of(by, workload, rows, launches_per_step_of=1):
     return roofline
 
 
-def cold_steps(job, torch, device, steps=5, flush_bytes=1 << 30):
+def cold_steps(job, torch, device, steps=5, flush_bytes=1 << 30, per_kernel_out=None):
     """Mean device time of a decode whose inputs are not in any cache: between
     steps 1 GiB is written (four times the 256 MB memory-side cache), outside the
     events that bracket each decode.  A reader decodes every stripe once, so this
@@ -416,8 +416,15 @@ def cold_steps(job, torch, device, steps=5, flush_bytes=1 << 30):
         b.record()
         flush.fill_(2)
     torch.cuda.synchronize(device)
+    ms = sum(a.elapsed_time(b) for a, b in evs) / steps
+    if per_kernel_out is not None:  # the same again with the per-launch events, for the cold time of every launch
+        job.profile_begin(steps)
+        for s in range(steps):
+            flush.fill_(3)
+            job.decode_profiled(s)
+        per_kernel_out.extend(kernel_table(by_kernel(job.launch_list, job.profile_end())))
     del flush
-    return sum(a.elapsed_time(b) for a, b in evs) / steps
+    return ms
 
 
 def plan_fields(job, ms_per_step, cold_ms=None):
@@ -453,7 +460,8 @@ def short_run(workload, rows, device, torch, steps=5, warmup=2):
     job.status()
     by = by_kernel(job.launch_list, ms)
     whole = (job.encoded + job.decoded) / (sum(ms) * 1e-3) / 1e9 if sum(ms) > 0 else 0.0
-    cold_ms = cold_steps(job, torch, device, steps)
+    cold_kernels = []
+    cold_ms = cold_steps(job, torch, device, steps, per_kernel_out=cold_kernels)
     job.status()
     res = {
         "workload": WORKLOAD_TEXT[workload].format(rows=rows), "value": round(job.decoded / dt / 1e9, 2), "unit": "GB/s",
@@ -463,7 +471,8 @@ def short_run(workload, rows, device, torch, steps=5, warmup=2):
         "whole_batch_algorithmic_gbs": round(whole, 1), "whole_batch_hbm_frac": round(whole / HBM_PEAK_GBS, 4),
         "cold_ms_per_step": round(cold_ms, 4), "cold_value": round(job.decoded / (cold_ms * 1e-3) / 1e9, 2),
         "cold_whole_batch_hbm_frac": round((job.encoded + job.decoded) / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-        "roofline": roofline_of(by, workload, rows), "kernels": kernel_table(by), "gen_seconds": round(job.gen_seconds, 1),
+        "roofline": roofline_of(by, workload, rows), "kernels": kernel_table(by), "cold_kernels": cold_kernels,
+        "gen_seconds": round(job.gen_seconds, 1),
     }
     res.update(plan_fields(job, dt * 1e3, cold_ms))
     if workload == "wide":

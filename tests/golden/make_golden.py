@@ -23,6 +23,14 @@ input the reference's tests feed (so the answer is known by construction):
   Varint ............ encodings/VarintEncoding.h:37-40, common/Varint.h:70-76
   chunk header ...... common/ChunkHeader.h:25-47
 
+Three origins (field "origin" of every case):
+  reference-held ..... every byte is what one of the reference's tests assembles field by field
+  reference-frame .... the frame (prefix, size fields, trailing value) and the expected output are
+                       what a test of the reference assembles / asserts; the child encodings inside
+                       it come from the reference's encoder there (forced to Trivial children) and
+                       are assembled here from the documented layout
+  self-assembled ..... put together here from the documented layout, with the reference tests' inputs
+
 Run:  python tests/golden/make_golden.py
 """
 import json
@@ -145,12 +153,18 @@ def varint_enc(vals, dt, base=None, vr=False):
 CASES = []
 
 
-def add(name, enc, dt, expected, nulls=None, vr=False, source="", origin="self-assembled"):
-    """origin: "reference-held" when the bytes are exactly what one of the reference's
-    own tests assembles field by field (the citing file:line is in `source`);
-    "self-assembled" when this script put them together from the documented layout."""
-    assert origin in ("reference-held", "self-assembled")
+def add(name, enc, dt, expected, nulls=None, vr=False, source="", origin="self-assembled", cursor=None, dictionary=None):
+    """origin: see the module docstring.  cursor: [(rows to skip, rows to materialize, expected)]
+    read after a reset().  dictionary: (size, entries as a set) the reference asserts for
+    Encoding::dictionarySize() / dictionaryEntries()."""
+    assert origin in ("reference-held", "reference-frame", "self-assembled")
     c = {"name": name, "data_type": dt, "varint_rows": vr, "hex": enc.hex(), "source": source, "origin": origin}
+    if cursor:
+        c["cursor"] = [{"skip": s, "materialize": m, "expected": list(e)} for s, m, e in cursor]
+    if dictionary:
+        size, entries = dictionary
+        c["dictionary_size"] = size
+        c["dictionary_entries"] = sorted(e.hex() if isinstance(e, bytes) else int(e) for e in entries)
     if dt == STR:
         c["expected_strings_hex"] = [s.hex() for s in expected]
     elif dt == BOOL:
@@ -265,6 +279,79 @@ def main():
     add("nullable_mainly_constant_dictionary",
         nullable(mainly_constant(nn2, I32, 1, dictionary([2, 3], I32)), mask[:9], I32), I32, full2, nulls=mask[:9],
         source="encodings/tests/EncodingTest.cpp:1295-1340")
+    # ---- frames and answers the reference's own tests hold ---------------------------
+    # MainlyConstantEncodingTest.cpp:388-464: prefix | writeString(SparseBool isCommon) | writeString(Trivial<int32>
+    # others) | write<uint32_t>(7); the test's Encoder<> writes children with Trivial leaves
+    # (encodings/tests/TestUtils.h:207-274).  Asserted: {7,7,20,7,40,7,7,70,7,7}; reset, skip(3), materialize(4) = {7,40,7,7}
+    ic = [True, True, False, True, False, True, True, False, True, True]
+    for vr in (False, True):
+        frame = (prefix(MC, I32, 10, vr) + struct.pack("<I", len(sparse_bool(ic, vr))) + sparse_bool(ic, vr) +
+                 struct.pack("<I", len(trivial([20, 40, 70], I32, vr))) + trivial([20, 40, 70], I32, vr) + struct.pack("<I", 7))
+        add("ref_mainly_constant_sparse_is_common" + ("_varint_rows" if vr else ""), frame, I32,
+            [7, 7, 20, 7, 40, 7, 7, 70, 7, 7], vr=vr, origin="reference-frame", cursor=[(3, 4, [7, 40, 7, 7])],
+            source="encodings/tests/MainlyConstantEncodingTest.cpp:388-464 (materializeSparseBoolIsCommon, useVarint = "
+                   + ("true" if vr else "false") + ")")
+    # ReadWithVisitorTest.cpp:3375-3483: Nullable<string>{Dictionary{Trivial, Trivial}, Trivial<bool>}, 50 rows, every
+    # fifth null, value kAlphabet[i % 3]; frame writeChar x2 | writeUint32 | writeString(values) | writeBytes(nulls)
+    # (:3434-3445).  Asserted: isNullable, dictionaryEnabled, alphabet[indices[i]] == kAlphabet[i % 3] on non-null rows
+    alpha3 = [b"alpha", b"bravo", b"charlie"]
+    mask50 = [i % 5 != 0 for i in range(50)]
+    rows50 = [alpha3[i % 3] if mask50[i] else b"" for i in range(50)]
+    add("ref_nullable_string_dictionary_50", nullable(dictionary([r for r, m in zip(rows50, mask50) if m], STR), mask50, STR), STR,
+        rows50, nulls=mask50, origin="reference-frame", dictionary=(3, alpha3),
+        source="encodings/tests/ReadWithVisitorTest.cpp:3375-3483 (readIndicesWithVisitorNullable)")
+    # ReadWithVisitorTest.cpp:3491-3600: 20 rows, rows 0,4,8,.. null; "delta" sits only in null rows and must not be
+    # in the dictionary: dictionarySize() == 3 (:3573)
+    vals4 = [b"delta", b"alpha", b"bravo", b"charlie"]
+    mask20 = [i % 4 != 0 for i in range(20)]
+    rows20 = [vals4[i % 4] if mask20[i] else b"" for i in range(20)]
+    add("ref_nullable_string_dictionary_masked_value", nullable(dictionary([r for r, m in zip(rows20, mask20) if m], STR), mask20, STR),
+        STR, rows20, nulls=mask20, origin="reference-frame", dictionary=(3, alpha3),
+        source="encodings/tests/ReadWithVisitorTest.cpp:3491-3600 (readIndicesWithVisitorNullableAlphabetValue)")
+    # EncodingTest.cpp:1057-1115 encodeNullableDictionary (frame :1092-1105) with the inputs of nullableBasics
+    # (:1513-1548: dictionarySize 3) and nullableAlphabetValue (:1550-1587: dictionarySize 2)
+    m5 = [True, True, False, True, True]
+    for tag, vals, size, where in (("basics", [1, 2, 1, 3, 2], 3, ":1513-1548"), ("alphabet_value", [1, 2, 3, 1, 2], 2, ":1550-1587")):
+        for dt, dn in ((I32, "i32"), (I64, "i64"), (U8, "u8")):
+            nn_ = [v for v, m in zip(vals, m5) if m]
+            add(f"ref_nullable_dictionary_{tag}_{dn}", nullable(dictionary(nn_, dt), m5, dt), dt,
+                [v if m else 0 for v, m in zip(vals, m5)], nulls=m5, origin="reference-frame", dictionary=(size, set(nn_)),
+                source="encodings/tests/EncodingTest.cpp:1057-1115 (frame :1092-1105), inputs of " + where)
+        names = {1: b"alpha", 2: b"bravo", 3: b"charlie"}
+        svals = [names[v] for v in vals]
+        nn_ = [v for v, m in zip(svals, m5) if m]
+        add(f"ref_nullable_dictionary_{tag}_string", nullable(dictionary(nn_, STR), m5, STR), STR,
+            [v if m else b"" for v, m in zip(svals, m5)], nulls=m5, origin="reference-frame", dictionary=(size, set(nn_)),
+            source="encodings/tests/EncodingTest.cpp:1057-1115 (frame :1092-1105), inputs of " + where)
+    # EncodingTest.cpp:1131-1205 serializeMainlyConstantWithConstantOthers (frame :1185-1202) with the input of
+    # mainlyConstantWithSingleOtherValue (:3022-3070): 20 rows of 100, rows 3, 7, 11, 15 = 42
+    d20 = [100] * 20
+    for i in (3, 7, 11, 15):
+        d20[i] = 42
+    for dt, dn in ((I32, "i32"), (I64, "i64"), (U16, "u16")):
+        add(f"ref_mainly_constant_constant_others_{dn}", mainly_constant(d20, dt, 100, constant(42, 4, dt)), dt, d20,
+            origin="reference-frame",
+            source="encodings/tests/EncodingTest.cpp:1131-1205 (frame :1185-1202), input of :3022-3070")
+    sd20 = [b"common_value"] * 20
+    for i in (3, 7, 11, 15):
+        sd20[i] = b"other_value"
+    add("ref_mainly_constant_constant_others_string",
+        mainly_constant(sd20, STR, b"common_value", constant(b"other_value", 4, STR)), STR, sd20, origin="reference-frame",
+        source="encodings/tests/EncodingTest.cpp:1131-1205 (frame :1185-1202), input of :3022-3070")
+    # EncodingTest.cpp:1207-1285 serializeMainlyConstantDictionary (frame :1264-1282) with the input of :1825-1855:
+    # 20 rows of 99, rows 3 and 15 = 1, row 7 = 2
+    e20 = [99] * 20
+    e20[3], e20[7], e20[15] = 1, 2, 1
+    for dt, dn in ((I32, "i32"), (I64, "i64")):
+        add(f"ref_mainly_constant_dictionary_others_{dn}", mainly_constant(e20, dt, 99, dictionary([1, 2, 1], dt)), dt, e20,
+            origin="reference-frame",
+            source="encodings/tests/EncodingTest.cpp:1207-1285 (frame :1264-1282), input of :1825-1855")
+    # EncodingTest.cpp:1296-1340 encodeNullableMainlyConstantDictionary with the input of :2015-2037
+    d7, m7 = [99, 1, 99, 2, 99, 99, 99], [True, True, False, True, True, True, True]
+    nn7 = [v for v, m in zip(d7, m7) if m]
+    add("ref_nullable_mainly_constant_dictionary", nullable(mainly_constant(nn7, I32, 99, dictionary([1, 2], I32)), m7, I32), I32,
+        [v if m else 0 for v, m in zip(d7, m7)], nulls=m7, origin="reference-frame",
+        source="encodings/tests/EncodingTest.cpp:1296-1340, input of :2015-2037")
     # ---- streams the reference's own tests assemble byte by byte --------------------
     # tools/tests/EncodingUtilitiesTest.cpp:42-70 buildTrivialUint32Stream: prefix | Uncompressed | raw u32
     for vals, where in (([10, 20, 30], ":194-201"), ([1, 2, 3], ":213-243"), ([10, 20], ":291-313 (encoded size 15)"),
@@ -319,12 +406,38 @@ def main():
                      (268435455, 4), (268435456, 5), (2**32 - 1, 5), (2**64 - 1, 10))]
     for e in varint_sizes:
         assert len(varint(e["value"])) == e["size"]
-    out = {"format": 2,
+    # run computation known answers (encodings/tests/RLETests.cpp:31-169): data -> (run lengths, run values);
+    # used both ways: the encoder must compute these runs, and an RLE of them must decode to the data
+    rle_runs = [{"source": "encodings/tests/RLETests.cpp:" + where, "data_type": dt, "data": d, "lengths": l, "values": v}
+                for where, dt, d, l, v in (
+                    ("42-56", I32, [42], [1], [42]),
+                    ("58-72", I32, [5, 5, 5, 5, 5], [5], [5]),
+                    ("74-88", I32, [1, 2, 3, 4, 5], [1, 1, 1, 1, 1], [1, 2, 3, 4, 5]),
+                    ("90-104", I32, [1, 1, 1, 2, 2, 3, 3, 3, 3], [3, 2, 4], [1, 2, 3]),
+                    ("106-120", I32, [-1, -1, 0, 0, 0, 1, 1], [2, 3, 2], [-1, 0, 1]),
+                    ("122-136", I64, [100, 100, 200, 200, 200], [2, 3], [100, 200]),
+                    ("138-153", U32, [0, 0, 1, 2, 2, 2], [2, 1, 3], [0, 1, 2]),
+                    ("155-169", I32, [1, 2, 1, 2, 1, 2], [1, 1, 1, 1, 1, 1], [1, 2, 1, 2, 1, 2]))]
+    for e in rle_runs:
+        assert runs_of(e["data"]) == (e["lengths"], e["values"])
+    # polarity and listed positions of SparseBool (encodings/tests/SparseBoolEncodingTest.cpp:145-216)
+    T, F = True, False
+    sparse_facts = [{"source": "encodings/tests/SparseBoolEncodingTest.cpp:" + where, "values": [int(b) for b in v],
+                     "sparse_value": int(sv), "positions": pos}
+                    for where, v, sv, pos in (
+                        ("145-172", [T, T, F, T, F, T, T, F, T, T], False, [2, 4, 7]),
+                        ("174-196", [F, T, F, F, F, F, T, F, F, F], True, [1, 6]),
+                        ("198-207", [T, T, F, T, T, T, T, T, T, T], False, [2]),
+                        ("209-216", [F, F, T, F, F, F, F, F, F, F], True, [2]))]
+    out = {"format": 3,
            "note": "hand-assembled; regenerate with tests/golden/make_golden.py.  origin = reference-held: the bytes are "
-                   "what one of the reference's own tests assembles field by field; self-assembled: put together here "
-                   "from the layout the reference documents",
+                   "what one of the reference's own tests assembles field by field; reference-frame: frame and expected "
+                   "output are a reference test's, the child encodings inside are assembled here; self-assembled: put "
+                   "together here from the layout the reference documents",
            "chunk_header_size": 5,
            "cases": CASES,
+           "rle_runs": {"origin": "reference-held", "entries": rle_runs},
+           "sparse_bool_facts": {"origin": "reference-held", "entries": sparse_facts},
            "headers": headers,
            "prefixes": prefixes,
            "chunk_headers": chunk_headers,

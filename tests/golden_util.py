@@ -29,8 +29,14 @@ def load_cases():
         if "expected_non_null" in c:
             nulls = np.array(c["expected_non_null"], dtype=bool)
         cases.append(dict(name=c["name"], enc=enc, data_type=dt, varint_rows=c["varint_rows"], expected=expected,
-                          non_null=nulls, source=c["source"]))
+                          non_null=nulls, source=c["source"], origin=c["origin"], cursor=c.get("cursor", []),
+                          dictionary_size=c.get("dictionary_size"), dictionary_entries=c.get("dictionary_entries")))
     return cases
+
+
+def load_doc():
+    with open(_PATH) as f:
+        return json.load(f)
 
 
 def assert_matches(case, values, nulls_bitmap, non_null_count, label):

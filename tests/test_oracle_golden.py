@@ -90,7 +90,10 @@ def _doc():
 def test_every_case_names_its_origin():
     doc = _doc()
     origins = [c["origin"] for c in doc["cases"]]
-    assert set(origins) == {"reference-held", "self-assembled"}
+    assert set(origins) == {"reference-held", "reference-frame", "self-assembled"}
+    framed = [c["name"] for c in doc["cases"] if c["origin"] == "reference-frame"]
+    assert len(framed) >= 19 and {"ref_mainly_constant_sparse_is_common", "ref_mainly_constant_sparse_is_common_varint_rows",
+                                  "ref_nullable_string_dictionary_50", "ref_nullable_string_dictionary_masked_value"} <= set(framed)
     held = [c["name"] for c in doc["cases"] if c["origin"] == "reference-held"]
     assert len(held) >= 10 and all(c["source"] for c in doc["cases"])
     # the reference-held families: Trivial<u32> / Constant<u32> of EncodingUtilitiesTest.cpp, encodeByteRounded in both prefix modes
@@ -147,3 +150,54 @@ def test_reference_held_block_bit_packing_header_walk():
         bad[9] = 200
         with pytest.raises(capi.NimbleCorruptError):
             capi.inflate_chunk(bytes(bad))
+
+
+# ---- frames and answers held by the reference's tests ------------------------------
+def _values_list(case, vals):
+    if case["data_type"] == W.STRING:
+        lengths, blob = vals
+        out, pos = [], 0
+        for n in lengths.tolist():
+            out.append(bytes(blob[pos:pos + n]))
+            pos += n
+        return out
+    return [int(v) for v in np.asarray(vals).astype(np.uint64)]
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c["cursor"]], ids=lambda c: c["name"])
+def test_oracle_cursor_reads_of_reference_frames(oracle, case):
+    """reset, skip(n), materialize(m) as MainlyConstantEncodingTest.cpp:456-462 asserts it."""
+    e = oracle.Encoding(case["enc"], case["varint_rows"])
+    e.materialize(e.row_count)
+    for step in case["cursor"]:
+        e.reset()
+        e.skip(step["skip"])
+        got = e.materialize(step["materialize"])
+        assert [int(v) for v in got.astype(np.int64)] == step["expected"], case["name"]
+
+
+def test_encoder_computes_the_reference_runs(oracle):
+    """RLETests.cpp:42-169: data -> (run lengths, run values); an RLE of those runs decodes to the data."""
+    import struct
+
+    for e in _doc()["rle_runs"]["entries"]:
+        dt = e["data_type"]
+        npt = W.physical_dtype(dt)
+        data = np.array(e["data"], dtype=np.int64).astype(npt)
+        lens = E.encode(E.Trivial(), np.array(e["lengths"], dtype=np.uint32), W.UINT32)
+        vals = E.encode(E.Trivial(), np.array(e["values"], dtype=np.int64).astype(npt), dt)
+        framed = E.prefix(W.RLE, dt, len(e["data"])) + struct.pack("<I", len(lens)) + lens + vals
+        assert E.encode(E.RLE(lengths=E.Trivial(), values=E.Trivial()), data, dt) == framed, e["source"]
+        got = oracle.Encoding(framed).materialize(len(e["data"]))
+        assert np.array_equal(got, data), e["source"]
+
+
+def test_sparse_bool_polarity_and_positions(oracle):
+    """SparseBoolEncodingTest.cpp:145-216: which value is listed, and where."""
+    for e in _doc()["sparse_bool_facts"]["entries"]:
+        bools = np.array(e["values"], dtype=bool)
+        enc = E.encode(E.SparseBool(indices=E.Trivial()), bools, W.BOOL)
+        assert enc[6] == e["sparse_value"], e["source"]
+        idx = oracle.Encoding(enc[7:]).materialize(len(e["positions"]) + 1)
+        assert idx.tolist() == e["positions"] + [len(e["values"])], e["source"]  # listed positions, then the row-count sentinel
+        assert np.array_equal(oracle.Encoding(enc).materialize(bools.size).astype(bool), bools)
