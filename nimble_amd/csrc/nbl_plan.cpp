@@ -916,6 +916,11 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
         const uint64_t bits = v.kind == COL_CONST ? 0u : (v.kind == COL_FBW ? v.width : 8u * es);
         one_wave = (uint64_t)v.rows * bits / 8 * trows * 3 <= (uint64_t)kWaveStageBytes * 2 * rows;
       }
+      // the rank-scatter bodies store the vector holding a column's last row whole:
+      // the destination must be a column of its own that starts on a 16-byte
+      // boundary and owns the bytes up to the next one (alloc_out / alloc_work
+      // hand out kAlign-sized blocks)
+      if (!nn.is_bool && (d.self.off % 16 != 0 || kAlign % 16 != 0)) fail(NBL_ERR_ARGUMENT, "rank-scatter destination is not a column of its own");
       const bool lds_dict = lds_dictionary && (d.flags & NF_DICT_VALUES) && es == 8 && d.c0.rows > kTileBytes / 8 && d.c0.rows <= kDictLdsEntries;
       if (nn.is_bool) add_step(fin, K_SELECT_BITS, 0, dn, nt);
       else if (lds_dict) add_step(fin, K_DICT_LDS, es, dn, div_up32(nt, kDictLdsTiles));

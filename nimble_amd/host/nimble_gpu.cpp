@@ -110,8 +110,12 @@ void copyBits(void* dst, uint64_t d, const void* src, uint64_t s, uint64_t n) {
 struct DeviceBuffer {
   void* ptr = nullptr;
   size_t cap = 0;
-  void reserve(size_t n) {
+  // Grows with a quarter of headroom, so a loop over stripes of one shape never
+  // reallocates.  `stream` = the stream whose queued work may still use the old
+  // block (a copy-back of the batch before last): waited for before it is freed.
+  void reserve(size_t n, hipStream_t stream = nullptr) {
     if (n <= cap) return;
+    if (ptr && stream) hipCheck(hipStreamSynchronize(stream), "hipStreamSynchronize");
     if (ptr) hipCheck(hipFree(ptr), "hipFree");
     ptr = nullptr;
     cap = 0;
@@ -195,11 +199,24 @@ class GpuContext {
   }
   int device_;
   std::shared_ptr<PinnedPool> pinned = std::make_shared<PinnedPool>();
-  // the slot of the next batch; the caller locks slot.mu around its use of the slot
-  Slot& nextSlot() { return slots_[next_.fetch_add(1, std::memory_order_relaxed) % kSlots]; }
-  void ensure(Slot& s) {
+  // The slot of the next batch, locked: the one whose turn it is, the other one
+  // when that is busy (two callers never queue on one slot while the other idles),
+  // and only then a wait for the first.  The device is current and the slot's
+  // stream exists on return.
+  std::unique_lock<std::mutex> acquire(Slot*& slot) {
+    const unsigned first = next_.fetch_add(1, std::memory_order_relaxed) % kSlots;
+    std::unique_lock<std::mutex> lock;
+    for (unsigned k = 0; k < kSlots && !lock.owns_lock(); ++k) {
+      slot = &slots_[(first + k) % kSlots];
+      lock = std::unique_lock<std::mutex>(slot->mu, std::try_to_lock);
+    }
+    if (!lock.owns_lock()) {
+      slot = &slots_[first];
+      lock = std::unique_lock<std::mutex>(slot->mu);
+    }
     hipCheck(hipSetDevice(device_), "hipSetDevice");
-    if (!s.stream) hipCheck(hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking), "hipStreamCreate");
+    if (!slot->stream) hipCheck(hipStreamCreateWithFlags(&slot->stream, hipStreamNonBlocking), "hipStreamCreate");
+    return lock;
   }
 
  private:
@@ -490,18 +507,47 @@ void parallelFor(size_t n, uint64_t bytes, F&& fn) {
 
 struct PlanHolder {
   nbl_plan* p = nullptr;
+  PlanHolder() = default;
+  PlanHolder(const PlanHolder&) = delete;
+  PlanHolder& operator=(const PlanHolder&) = delete;
+  PlanHolder(PlanHolder&& o) noexcept : p(o.p) { o.p = nullptr; }
+  PlanHolder& operator=(PlanHolder&& o) noexcept {
+    if (this != &o) {
+      nbl_plan_free(p);
+      p = o.p;
+      o.p = nullptr;
+    }
+    return *this;
+  }
   ~PlanHolder() { nbl_plan_free(p); }
 };
 
-// plan + H2D + decode + D2H for chunks given as (pointer, size) pairs.
-std::vector<std::unique_ptr<Encoding>> decodeChunks(GpuContext& ctx, const std::vector<std::string_view>& chunks,
-                                                    const GpuEncodingFactory::StringBufferFactory& sbf, const Options& opts) {
-  std::vector<std::unique_ptr<Encoding>> result;
-  if (chunks.empty()) return result;
-  // the chunks are packed (16-byte aligned starts) into one pinned staging block:
-  // the image the device arena receives.  Chunks with Zstd / LZ4 leaf payloads
-  // (the reference writer's default) are inflated straight into it.
-  nbl_options o{sizeof(nbl_options), opts.useVarintRowCount ? 1u : 0u, opts.keepDictionary ? NBL_PLAN_KEEP_DICTIONARY : 0u};
+nbl_options planOptions(const Options& opts) {
+  nbl_options o{};
+  o.struct_size = sizeof(nbl_options);
+  o.use_varint_row_count = opts.useVarintRowCount ? 1u : 0u;
+  o.flags = opts.keepDictionary ? NBL_PLAN_KEEP_DICTIONARY : 0u;
+  return o;
+}
+
+// The encoded bytes of a batch on their way to a slot's arena, and the plan over them.
+struct StagedBatch {
+  PlanHolder plan;
+  nbl_plan_info info{};
+  std::shared_ptr<uint8_t> staging;  // pinned image of the arena; alive until the copy has been waited for
+};
+
+// Packs the chunks (16-byte aligned starts) into one pinned staging block -- the
+// image the device arena receives; chunks with Zstd / LZ4 leaf payloads, the
+// reference writer's default, are inflated straight into it -- and copies it to
+// slot.arena on slot.stream.  The block is filled and sent in slices of about
+// 32 MiB: while the copy engine moves one slice, the host threads fill the
+// next, so a stripe pays the longer of the two instead of their sum.  The plan
+// is made once the last slice is on its way (the header walk reads the staged
+// bytes), i.e. under the tail of the transfer.  The slot is locked by the caller.
+StagedBatch stageBatch(GpuContext& ctx, GpuContext::Slot& slot, const std::vector<std::string_view>& chunks, const Options& opts) {
+  StagedBatch b;
+  const nbl_options o = planOptions(opts);
   std::vector<uint64_t> offs(chunks.size()), sizes(chunks.size());
   std::vector<uint8_t> inflate(chunks.size(), 0);
   uint64_t total = 0;
@@ -513,44 +559,61 @@ std::vector<std::unique_ptr<Encoding>> decodeChunks(GpuContext& ctx, const std::
     sizes[i] = inflated ? inflated : chunks[i].size();
     total += (sizes[i] + 15) & ~uint64_t(15);
   }
-  std::shared_ptr<uint8_t> staging = ctx.pinned->acquire(total);
-  parallelFor(chunks.size(), total, [&](size_t i) {
-    if (inflate[i]) {
-      uint64_t written = 0;
-      check(nbl_chunk_inflate(reinterpret_cast<const uint8_t*>(chunks[i].data()), chunks[i].size(), &o, staging.get() + offs[i],
-                              sizes[i], &written));
-    } else {
-      memcpy(staging.get() + offs[i], chunks[i].data(), chunks[i].size());
-    }
-  });
+  b.staging = ctx.pinned->acquire(total);
+  slot.arena.reserve(total + 64, slot.stream);  // + the slop nbl_plan_info::arena_bytes asks for behind the last chunk
+  constexpr uint64_t kSlice = 32ull << 20;
+  for (size_t first = 0; first < chunks.size();) {
+    size_t last = first;
+    uint64_t bytes = 0;
+    while (last < chunks.size() && (bytes == 0 || bytes + sizes[last] <= kSlice)) bytes += (sizes[last++] + 15) & ~uint64_t(15);
+    parallelFor(last - first, bytes, [&](size_t k) {
+      const size_t i = first + k;
+      if (inflate[i]) {
+        uint64_t written = 0;
+        check(nbl_chunk_inflate(reinterpret_cast<const uint8_t*>(chunks[i].data()), chunks[i].size(), &o, b.staging.get() + offs[i],
+                                sizes[i], &written));
+      } else {
+        memcpy(b.staging.get() + offs[i], chunks[i].data(), chunks[i].size());
+      }
+    });
+    hipCheck(hipMemcpyAsync(static_cast<uint8_t*>(slot.arena.ptr) + offs[first], b.staging.get() + offs[first], bytes,
+                            hipMemcpyHostToDevice, slot.stream), "H2D");
+    first = last;
+  }
+  check(nbl_plan_batch(b.staging.get(), offs.data(), sizes.data(), (uint32_t)chunks.size(), &o, &b.plan.p));
+  check(nbl_plan_get_info(b.plan.p, &b.info));
+  if (b.info.arena_bytes > slot.arena.cap) throw NimbleError(NBL_ERR_ARGUMENT, "arena smaller than the plan asks for");
+  return b;
+}
 
-  PlanHolder plan;
-  check(nbl_plan_batch(staging.get(), offs.data(), sizes.data(), (uint32_t)chunks.size(), &o, &plan.p));
-  nbl_plan_info info;
-  check(nbl_plan_get_info(plan.p, &info));
-
-  auto hostOut = std::make_shared<OutputCopy>(ctx.pinned->acquire(info.out_bytes));
+// plan + H2D + decode + D2H for chunks given as (pointer, size) pairs.
+std::vector<std::unique_ptr<Encoding>> decodeChunks(GpuContext& ctx, const std::vector<std::string_view>& chunks,
+                                                    const GpuEncodingFactory::StringBufferFactory& sbf, const Options& opts) {
+  std::vector<std::unique_ptr<Encoding>> result;
+  if (chunks.empty()) return result;
+  StagedBatch b;
+  std::shared_ptr<OutputCopy> hostOut;
   {
-    GpuContext::Slot& slot = ctx.nextSlot();
-    std::lock_guard<std::mutex> lock(slot.mu);
-    ctx.ensure(slot);
-    slot.arena.reserve(info.arena_bytes);
-    slot.out.reserve(info.out_bytes);
-    slot.work.reserve(info.work_bytes);
-    hipCheck(hipMemcpyAsync(slot.arena.ptr, staging.get(), total, hipMemcpyHostToDevice, slot.stream), "H2D");
-    check(nbl_plan_upload(plan.p, slot.work.ptr, slot.stream));
-    check(nbl_decode_batch_device(plan.p, slot.arena.ptr, slot.out.ptr, slot.work.ptr, slot.stream));
+    GpuContext::Slot* slotp = nullptr;
+    std::unique_lock<std::mutex> lock = ctx.acquire(slotp);
+    GpuContext::Slot& slot = *slotp;
+    b = stageBatch(ctx, slot, chunks, opts);
+    hostOut = std::make_shared<OutputCopy>(ctx.pinned->acquire(b.info.out_bytes));
+    slot.out.reserve(b.info.out_bytes, slot.stream);
+    slot.work.reserve(b.info.work_bytes, slot.stream);
+    check(nbl_plan_upload(b.plan.p, slot.work.ptr, slot.stream));
+    check(nbl_decode_batch_device(b.plan.p, slot.arena.ptr, slot.out.ptr, slot.work.ptr, slot.stream));
     // synchronises the slot's stream: inconsistent payloads are reported before anything is handed out
-    check(nbl_decode_status(plan.p, slot.work.ptr, slot.stream));
+    check(nbl_decode_status(b.plan.p, slot.work.ptr, slot.stream));
     // the copy back runs on while the caller already reads the first chunks and
     // while the next batch is copied in and decoded on the other slot; the batch
     // after that queues behind this copy on this slot's stream
-    hostOut->enqueue(slot.out.ptr, info.out_bytes, slot.stream);
+    hostOut->enqueue(slot.out.ptr, b.info.out_bytes, slot.stream);
   }
   result.reserve(chunks.size());
   for (uint32_t c = 0; c < chunks.size(); ++c) {
     nbl_chunk_layout lay;
-    check(nbl_plan_get_chunk_layout(plan.p, c, &lay));
+    check(nbl_plan_get_chunk_layout(b.plan.p, c, &lay));
     result.push_back(std::make_unique<GpuEncoding>(lay, hostOut, sbf));
   }
   return result;
@@ -577,48 +640,22 @@ std::unique_ptr<DeviceBatch> decodeChunksToDevice(const std::shared_ptr<GpuConte
   auto batch = std::make_unique<DeviceBatchImpl>();
   batch->ctx = ctxp;
   if (chunks.empty()) return batch;
-  nbl_options o{sizeof(nbl_options), opts.useVarintRowCount ? 1u : 0u, opts.keepDictionary ? NBL_PLAN_KEEP_DICTIONARY : 0u};
-  std::vector<uint64_t> offs(chunks.size()), sizes(chunks.size());
-  std::vector<uint8_t> inflate(chunks.size(), 0);
-  uint64_t total = 0;
-  for (size_t i = 0; i < chunks.size(); ++i) {
-    uint64_t inflated = 0;
-    check(nbl_chunk_inflated_size(reinterpret_cast<const uint8_t*>(chunks[i].data()), chunks[i].size(), &o, &inflated));
-    inflate[i] = inflated != 0;
-    offs[i] = total;
-    sizes[i] = inflated ? inflated : chunks[i].size();
-    total += (sizes[i] + 15) & ~uint64_t(15);
-  }
-  std::shared_ptr<uint8_t> staging = ctx.pinned->acquire(total);
-  parallelFor(chunks.size(), total, [&](size_t i) {
-    if (inflate[i]) {
-      uint64_t written = 0;
-      check(nbl_chunk_inflate(reinterpret_cast<const uint8_t*>(chunks[i].data()), chunks[i].size(), &o, staging.get() + offs[i],
-                              sizes[i], &written));
-    } else {
-      memcpy(staging.get() + offs[i], chunks[i].data(), chunks[i].size());
-    }
-  });
-  PlanHolder plan;
-  check(nbl_plan_batch(staging.get(), offs.data(), sizes.data(), (uint32_t)chunks.size(), &o, &plan.p));
-  nbl_plan_info info;
-  check(nbl_plan_get_info(plan.p, &info));
+  StagedBatch b;
   {
-    GpuContext::Slot& slot = ctx.nextSlot();
-    std::lock_guard<std::mutex> lock(slot.mu);
-    ctx.ensure(slot);
-    slot.arena.reserve(info.arena_bytes);
-    slot.work.reserve(info.work_bytes);
-    batch->out.reserve(info.out_bytes);   // owned by the batch: it outlives this call
-    batch->outBytes = info.out_bytes;
+    GpuContext::Slot* slotp = nullptr;
+    std::unique_lock<std::mutex> lock = ctx.acquire(slotp);
+    GpuContext::Slot& slot = *slotp;
+    b = stageBatch(ctx, slot, chunks, opts);
+    slot.work.reserve(b.info.work_bytes, slot.stream);
+    batch->out.reserve(b.info.out_bytes);   // owned by the batch: it outlives this call
+    batch->outBytes = b.info.out_bytes;
     batch->stream_ = slot.stream;
-    hipCheck(hipMemcpyAsync(slot.arena.ptr, staging.get(), total, hipMemcpyHostToDevice, slot.stream), "H2D");
-    check(nbl_plan_upload(plan.p, slot.work.ptr, slot.stream));
-    check(nbl_decode_batch_device(plan.p, slot.arena.ptr, batch->out.ptr, slot.work.ptr, slot.stream));
-    check(nbl_decode_status(plan.p, slot.work.ptr, slot.stream));  // synchronises the slot's stream
+    check(nbl_plan_upload(b.plan.p, slot.work.ptr, slot.stream));
+    check(nbl_decode_batch_device(b.plan.p, slot.arena.ptr, batch->out.ptr, slot.work.ptr, slot.stream));
+    check(nbl_decode_status(b.plan.p, slot.work.ptr, slot.stream));  // synchronises the slot's stream
   }
   batch->layouts.resize(chunks.size());
-  for (uint32_t c = 0; c < chunks.size(); ++c) check(nbl_plan_get_chunk_layout(plan.p, c, &batch->layouts[c]));
+  for (uint32_t c = 0; c < chunks.size(); ++c) check(nbl_plan_get_chunk_layout(b.plan.p, c, &batch->layouts[c]));
   return batch;
 }
 

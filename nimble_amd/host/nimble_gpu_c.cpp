@@ -292,4 +292,41 @@ void* nblh_tablet_decode_stripe(void* factory, void* t, uint32_t stripe, uint32_
   return h;
 }
 
+// ---- all stripes of a file over several devices -----------------------------
+// owner[i] = index of the device (0 .. devices - 1) stripe i is assigned to
+int nblh_assign_stripes(const uint64_t* sizes, uint32_t n, uint32_t devices, uint32_t* owner) {
+  return guard([&] {
+    const auto owned = GpuTabletDecoder::assignStripes(std::vector<uint64_t>(sizes, sizes + n), devices);
+    for (size_t d = 0; d < owned.size(); ++d)
+      for (uint32_t s : owned[d]) owner[s] = (uint32_t)d;
+  });
+}
+void* nblh_tablet_decoder_create(void* t, const int32_t* devices, uint32_t n_devices, int flags, uint32_t lookahead) {
+  GpuTabletDecoder* d = nullptr;
+  guard([&] {
+    Options o;
+    o.useVarintRowCount = (flags & 1) != 0;
+    o.keepDictionary = (flags & 2) != 0;
+    d = new GpuTabletDecoder(*static_cast<Tablet*>(t), std::vector<int>(devices, devices + n_devices), o, lookahead);
+  });
+  return d;
+}
+void nblh_tablet_decoder_free(void* d) { delete static_cast<GpuTabletDecoder*>(d); }
+int nblh_tablet_decoder_device_of(void* d, uint32_t stripe, int32_t* device) {
+  return guard([&] { *device = static_cast<GpuTabletDecoder*>(d)->deviceOf(stripe); });
+}
+// blocks until the stripe is decoded; the returned handle is a stripe handle (nblh_stripe_*)
+void* nblh_tablet_decoder_take(void* d, uint32_t stripe, uint32_t* ids, uint32_t capacity, uint32_t* n) {
+  StripeHandle* h = new StripeHandle();
+  const int rc = guard([&] {
+    auto* D = static_cast<GpuTabletDecoder*>(d);
+    const auto sid = D->streamIds(stripe);
+    *n = (uint32_t)sid.size();
+    for (size_t i = 0; i < sid.size() && i < capacity; ++i) ids[i] = sid[i];
+    h->dec = D->take(stripe);
+  });
+  if (rc != 0) { delete h; return nullptr; }
+  return h;
+}
+
 }  // extern "C"

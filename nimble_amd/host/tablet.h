@@ -11,6 +11,7 @@
 #pragma once
 
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <string_view>
 #include <vector>
@@ -53,6 +54,55 @@ class Tablet {
   std::vector<uint64_t> stripeOffsets_;
   std::vector<Group> groups_;
   std::vector<std::pair<std::string, std::string_view>> optional_;
+};
+
+// Every stripe of a file decoded across several GPUs.  A stripe is a
+// self-contained set of streams (dwio/nimble/tablet/TabletReader.h:210-219) and
+// an Encoding reads nothing outside its own bytes, so nothing moves between
+// devices: stripes are dealt to the devices by longest-processing-time-first
+// over their byte sizes (the footer's Stripes.sizes, tablet/Footer.fbs:26-31),
+// each device has a GpuEncodingFactory and a host thread of its own that walks
+// its stripes in ascending order (plan, stage, decode, copy back), and the
+// stripes are handed out by index, i.e. in row order, as the reference reader
+// walks them (VeloxReader::loadNextStripe, velox/VeloxReader.cpp:299-353; files
+// are split across readers by stripe, :229-273).  Completion is a join; there is
+// no collective.  A device may be named more than once (two contexts on one GPU).
+class GpuTabletDecoder {
+ public:
+  // `tablet` (and the file bytes it views) must outlive this object.  The device
+  // threads start at once and run at most `lookahead` stripes per device ahead
+  // of the lowest stripe not yet taken (0 = no bound: the whole file is decoded
+  // and held in host memory until taken).
+  GpuTabletDecoder(const Tablet& tablet, std::vector<int> devices, Options options = {}, uint32_t lookahead = 2);
+  ~GpuTabletDecoder();
+  GpuTabletDecoder(const GpuTabletDecoder&) = delete;
+  GpuTabletDecoder& operator=(const GpuTabletDecoder&) = delete;
+
+  // Per device, its stripes in ascending order: stripes in decreasing size, each
+  // to the device with the fewest bytes so far (ties: fewest stripes, then the
+  // lowest device).  Deterministic: any process computes the same assignment
+  // from the footer without communicating.
+  static std::vector<std::vector<uint32_t>> assignStripes(const std::vector<uint64_t>& stripeSizes, size_t devices);
+  const std::vector<std::vector<uint32_t>>& assignment() const { return assignment_; }
+  int deviceOf(uint32_t stripe) const { return devices_.at(owner_.at(stripe)); }
+  uint32_t stripeCount() const { return (uint32_t)owner_.size(); }
+
+  // Stream ids of the stripe's non-empty streams, in the order of the decoders
+  // of the GpuStripeDecoder that take() returns.
+  std::vector<uint32_t> streamIds(uint32_t stripe) const;
+  // Blocks until the stripe is decoded and hands it over (once per stripe; take
+  // them in ascending order when a look-ahead bound is set).  Rethrows what the
+  // stripe's decode threw.
+  std::unique_ptr<GpuStripeDecoder> take(uint32_t stripe);
+
+ private:
+  struct State;
+  void startThreads();
+  const Tablet& tablet_;
+  std::vector<int> devices_;
+  std::vector<std::vector<uint32_t>> assignment_;
+  std::vector<uint32_t> owner_;  // per stripe: index into devices_
+  std::unique_ptr<State> state_;
 };
 
 }  // namespace nimble_amd

@@ -45,8 +45,12 @@ def run_length_values(rng, n: int, lo: int = 10, hi: int = 60, card: int = 1000,
     return np.repeat(vals, lens)[:n]
 
 
-def fbw_rle_table(rows: int = 10_000_000, seed: int = 42):
-    """Benchmark table "10M-row int32/int64 columns, fixed-bit-width + RLE cascades"."""
+def fbw_rle_table(rows: int = 10_000_000, seed: int = 42, compression=None):
+    """Benchmark table "10M-row int32/int64 columns, fixed-bit-width + RLE cascades".
+    compression = "zstd" | "lz4": every bit-packed payload is written compressed, the
+    reference writer's default for leaves (compression/CompressionPolicy.h:115-143;
+    here unconditionally, without its 2% gain test) -- the host layer's input only,
+    the planner itself takes uncompressed payloads."""
     rng = np.random.default_rng(seed)
     chunks = []
     for dtype, widths, npt in ((W.INT32, FBW_WIDTHS_32, np.uint32), (W.INT64, FBW_WIDTHS_64, np.uint64)):
@@ -60,11 +64,12 @@ def fbw_rle_table(rows: int = 10_000_000, seed: int = 42):
                     vals[0] = base
                     vals[1] = (base + ((1 << w) - 1)) & ((1 << (8 * es)) - 1)
                 chunks.append((f"fbw/{W.DATA_TYPE_NAMES[dtype]}/w{w}/r{pos}",
-                               E.encode(E.FixedBitWidth(bit_width=w, baseline=base), vals, dtype)))
+                               E.encode(E.FixedBitWidth(bit_width=w, baseline=base, compression=compression), vals, dtype)))
         for exact in (False, True):
             for pos, n in _chunks(rows, es):
                 vals = run_length_values(rng, n).astype(npt)
-                spec = E.RLE(lengths=E.FixedBitWidth(exact_bits=exact), values=E.FixedBitWidth(exact_bits=exact))
+                spec = E.RLE(lengths=E.FixedBitWidth(exact_bits=exact, compression=compression),
+                             values=E.FixedBitWidth(exact_bits=exact, compression=compression))
                 chunks.append((f"rle/{W.DATA_TYPE_NAMES[dtype]}/{'exact' if exact else 'bytes'}/r{pos}",
                                E.encode(spec, vals, dtype)))
     return chunks
@@ -240,6 +245,7 @@ def wide_table_stripe(stripe: int = 0, columns: int = 5000, rows: int = 100_000)
 
 WORKLOADS = {
     "fbw_rle": lambda rows, seed: fbw_rle_table(rows, seed),
+    "fbw_rle_zstd": lambda rows, seed: fbw_rle_table(rows, seed, compression="zstd"),
     "dict_string": lambda rows, seed: dict_string_table(rows, seed),
     "mixed": lambda rows, seed: mixed_table_stripe(seed, rows),
     "wide": lambda rows, seed: wide_table_stripe(seed, 5000, rows),

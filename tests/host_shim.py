@@ -103,6 +103,13 @@ def lib():
         L.nblh_tablet_optional_section.argtypes = [vp, C.c_char_p, C.POINTER(vp), u64p]
         L.nblh_tablet_decode_stripe.restype = vp
         L.nblh_tablet_decode_stripe.argtypes = [vp, vp, u32, vp, u32, C.POINTER(u32)]
+        L.nblh_assign_stripes.argtypes = [vp, u32, u32, vp]
+        L.nblh_tablet_decoder_create.restype = vp
+        L.nblh_tablet_decoder_create.argtypes = [vp, vp, u32, i32, u32]
+        L.nblh_tablet_decoder_free.argtypes = [vp]
+        L.nblh_tablet_decoder_device_of.argtypes = [vp, u32, C.POINTER(i32)]
+        L.nblh_tablet_decoder_take.restype = vp
+        L.nblh_tablet_decoder_take.argtypes = [vp, u32, vp, u32, C.POINTER(u32)]
         _lib = L
     return _lib
 
@@ -378,6 +385,46 @@ class Tablet:
         sd = StripeDecoder.__new__(StripeDecoder)
         sd._factory, sd._streams, sd._h, sd._keep = factory, [], h, self
         return sd, ids[: n.value].tolist()
+
+
+def assign_stripes(sizes, devices):
+    """GpuTabletDecoder::assignStripes: per device, its stripes ascending."""
+    a = np.asarray(sizes, dtype=np.uint64)
+    owner = np.zeros(max(a.size, 1), dtype=np.uint32)
+    _chk(lib().nblh_assign_stripes(_p(a), a.size, devices, _p(owner)))
+    return [[s for s in range(a.size) if owner[s] == d] for d in range(devices)]
+
+
+class TabletDecoder:
+    """GpuTabletDecoder: all stripes of a Tablet over a list of devices."""
+
+    def __init__(self, tablet: Tablet, devices, varint_rows=False, keep_dictionary=False, lookahead=2):
+        self._tablet = tablet
+        dev = np.asarray(devices, dtype=np.int32)
+        self._h = lib().nblh_tablet_decoder_create(tablet._h, _p(dev), dev.size, int(varint_rows) | (2 if keep_dictionary else 0), lookahead)
+        if not self._h:
+            _chk(-1)
+
+    def device_of(self, stripe):
+        d = C.c_int32()
+        _chk(lib().nblh_tablet_decoder_device_of(self._h, stripe, C.byref(d)))
+        return d.value
+
+    def take(self, stripe):
+        """(StripeDecoder-like object, stream ids) of a decoded stripe; blocks until it is ready."""
+        ids = np.zeros(max(self._tablet.stripe_info(stripe)[3], 1), dtype=np.uint32)
+        n = C.c_uint32()
+        h = lib().nblh_tablet_decoder_take(self._h, stripe, _p(ids), ids.size, C.byref(n))
+        if not h:
+            _chk(-1)
+        sd = StripeDecoder.__new__(StripeDecoder)
+        sd._factory, sd._streams, sd._h, sd._keep = None, [], h, self
+        return sd, ids[: n.value].tolist()
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().nblh_tablet_decoder_free(self._h)
+            self._h = None
 
 
 class DeviceBatch:

@@ -108,3 +108,64 @@ def test_stripe_from_file_decodes_on_the_gpu(gpu):
         blob = np.zeros(max(int(total), 1), dtype=np.uint8)
         host_shim.lib().nblh_sv_flatten(sv.ctypes.data, n, lengths.ctypes.data, blob.ctypes.data)
         assert np.array_equal(lengths, c.lengths) and np.array_equal(blob[: int(total)], c.blob)
+
+
+def test_stripe_assignment_matches_the_multi_process_one():
+    """GpuTabletDecoder::assignStripes (one process, several devices) deals stripes
+    exactly as shard.assign_stripes does for one rank per GPU."""
+    import host_shim
+    from nimble_amd import shard
+
+    rng = np.random.default_rng(8)
+    for n_stripes in (0, 1, 2, 7, 16, 100):
+        for devices in (1, 2, 3, 8):
+            for sizes in (rng.integers(1, 1 << 28, n_stripes), np.full(n_stripes, 12345), rng.integers(1, 4, n_stripes)):
+                assert host_shim.assign_stripes(sizes, devices) == shard.assign_stripes([int(x) for x in sizes], devices)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("devices,lookahead", [([0], 2), ([0, 0], 2), ([0, 0, 0], 1), ([0, 0], 0)])
+def test_all_stripes_of_a_file_over_several_device_contexts(gpu, oracle, devices, lookahead):
+    """Every stripe of a file decoded by GpuTabletDecoder -- one host thread and
+    factory per entry of `devices` (the one GPU named several times: several
+    contexts on it), stripes handed out in row order -- against the oracle's
+    decode of the same stream bytes."""
+    import host_shim
+    from nimble_amd import shard
+
+    rng = np.random.default_rng(9)
+    data, stripes, expect = _file(rng, n_stripes=7, rows=2500)
+    t = host_shim.Tablet(data)
+    td = host_shim.TabletDecoder(t, devices, lookahead=lookahead)
+    sizes = [t.stripe_info(i)[2] for i in range(t.stripe_count)]
+    owned = shard.assign_stripes(sizes, len(devices))
+    for i in range(t.stripe_count):
+        assert td.device_of(i) == 0 and any(i in o for o in owned)
+        dec, ids = td.take(i)
+        assert ids == [0, 1, 3]
+        n = stripes[i][0]
+        for k, sid in enumerate(ids):
+            ref = oracle.StreamDecoder(stripes[i][1][sid])
+            if sid == 3:
+                sv = np.zeros(2 * n, dtype=np.uint64)
+                assert dec.stream(k).next(n, sv)[0] == n
+                lengths = np.zeros(n, dtype=np.uint32)
+                total = host_shim.lib().nblh_sv_total(sv.ctypes.data, n)
+                blob = np.zeros(max(int(total), 1), dtype=np.uint8)
+                host_shim.lib().nblh_sv_flatten(sv.ctypes.data, n, lengths.ctypes.data, blob.ctypes.data)
+                c = expect[i][3]
+                assert np.array_equal(lengths, c.lengths) and np.array_equal(blob[: int(total)], c.blob)
+                continue
+            dt = np.uint64 if sid == 0 else np.uint32
+            got, want = np.zeros(n, dtype=dt), np.zeros(n, dtype=dt)
+            gn, wn = np.zeros((n + 7) // 8 + 8, dtype=np.uint8), np.zeros((n + 7) // 8 + 8, dtype=np.uint8)
+            res = dec.stream(k).next(n, got, gn)
+            assert res == ref.next(n, want, wn)
+            if res[1]:  # nulls were asked for: compare the bitmap and the rows that have a value
+                live = np.unpackbits(wn, bitorder="little")[:n].astype(bool)
+                assert np.array_equal(np.unpackbits(gn, bitorder="little")[:n].astype(bool), live)
+                assert np.array_equal(got[live], want[live])
+            else:
+                assert np.array_equal(got, want)
+    with pytest.raises(host_shim.HostError, match="taken twice"):
+        td.take(0)
