@@ -426,6 +426,7 @@ enum ReaderKind : int {
 template <int RK, int CES>
 struct Reader {
   using T = elem_t<CES>;
+  static constexpr int kKind = RK;
   const uint8_t* p;
   T base;
   uint32_t w;
@@ -908,9 +909,10 @@ __device__ __forceinline__ uint32_t chain_exclusive(const KArgs& a, const NodeDe
 // Sum of `s` over the aligned group of `sub` consecutive threads (sub = 32, 64,
 // 128 or 256, workgroup uniform; tmp holds 4 words; every thread calls).
 __device__ __forceinline__ uint32_t group_sum(uint32_t s, uint32_t sub, uint32_t* tmp) {
-#pragma unroll
-  for (int d = 16; d > 0; d >>= 1) s += __shfl_xor(s, d, 64);  // sum of the aligned 32-lane group
-  if (sub >= 64) s += __shfl_xor(s, 32, 64);                    // sum of the wave
+  // one scan with data-parallel-primitive moves gives both halves of the wave (no LDS permutes)
+  const uint32_t incl = wave_incl_scan(s);
+  const uint32_t whole = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63), low = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);
+  s = sub >= 64 ? whole : (lane_id() < 32 ? low : whole - low);
   if (sub > 64) {
     __syncthreads();
     if (lane_id() == 0) tmp[wave_id()] = s;
@@ -1317,9 +1319,9 @@ template <uint32_t W>
 __device__ __forceinline__ void sparse_bits_tile(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
   constexpr uint32_t WPT = W / kBlock;
   constexpr uint32_t TR = W * 64;  // rows per tile
-  static_assert(W % kBlock == 0 && W * 8 + 8 <= kSmemBytes && kBlock == kBitTileWords, "sparse tile geometry");
-  uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem);
-  uint32_t* s_k = reinterpret_cast<uint32_t*>(smem + W * 8);
+  static_assert(W % kBlock == 0 && W * 8 + 16 <= kScratchOff && kBlock == kBitTileWords, "sparse tile geometry");
+  uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem);           // W words, then one spare word: bit TR takes what falls outside the tile
+  uint32_t* s_k = reinterpret_cast<uint32_t*>(smem + W * 8 + 8);
   const uint64_t rows = nd.rows;
   const uint32_t K = nd.c0.rows;
   const uint64_t p0 = (uint64_t)tile * TR;
@@ -1341,39 +1343,94 @@ __device__ __forceinline__ void sparse_bits_tile(const KArgs& a, const NodeDesc&
     }
 #pragma unroll
     for (uint32_t u = 0; u < WPT; ++u) s_bits[u * kBlock + threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_bits[W] = 0;
     __syncthreads();
     NBL_PHASE(smem, kSmemBytes, 1);  // descriptor, searches, zeroed tile
     const uint32_t lo = s_k[0], hi = s_k[1];
     uint32_t* bits32 = reinterpret_cast<uint32_t*>(s_bits);
-    // Eight positions per thread and round, and the next round's loads are
-    // issued before this round's positions are used: a column of R rounds
-    // waits for about one memory round trip instead of R.  Dense columns are
-    // bound by the instructions per position, so all of it is 32-bit work on
-    // top of a scalar base: positions relative to `lo` (a view), rows relative
-    // to the tile, one unsigned compare for "inside the tile".
-    constexpr uint32_t PPT = 8;
-    const uint32_t tile_row0 = (uint32_t)p0, span = (uint32_t)(p1 - p0);
+    // Dense columns are bound by the vector instructions per position, so the
+    // loop is pared down to them.  A listed row sets bit (row - first row of the
+    // tile); anything outside the tile -- the sentinel behind the last row, a
+    // position of damaged input -- is clamped onto the spare bit behind the
+    // tile's words instead of being tested for (a wrapped difference is large,
+    // so one unsigned minimum does both sides).  Eight positions per thread and
+    // round, the next round's loads issued before this round's are used: a
+    // column of R rounds waits for about one memory round trip instead of R.
+    constexpr uint32_t PPT = 8, ROUND = PPT * kBlock;
+    const uint32_t tile_row0 = (uint32_t)p0;
     const uint32_t cnt = hi > lo ? hi - lo : 0u;       // positions of this tile (<= its rows)
-    const auto list = rd.view(lo);
-    uint32_t pos[PPT], nxt[PPT];
-    auto fetch = [&](uint32_t (&dst)[PPT], uint32_t i0) {  // positions lo + i0 + u * kBlock
-#pragma unroll
-      for (uint32_t u = 0; u < PPT; ++u) {
-        const uint32_t i = i0 + u * kBlock;
-        dst[u] = list.at(i < cnt ? i : cnt - 1);
-      }
+    auto set_row = [&](uint32_t rel) {
+      const uint32_t q = rel < TR ? rel : TR;
+      atomicOr(&bits32[q >> 5], 1u << (q & 31));
     };
-    if (cnt) fetch(pos, threadIdx.x);
-    for (uint32_t r0 = 0; r0 < cnt; r0 += PPT * kBlock) {  // r0: workgroup uniform
-      const uint32_t i0 = r0 + threadIdx.x;
-      if (r0 + PPT * kBlock < cnt) fetch(nxt, i0 + PPT * kBlock);
+    using RD = decltype(rd);
+    constexpr bool kFast = RD::kKind == RK_FBW32 || RD::kKind == RK_PTR;
+    if constexpr (kFast) {
+      // A thread takes eight CONSECUTIVE positions of a round (2,048 positions),
+      // so the lanes of one instruction hold positions eight apart: their bits
+      // fall into different words, where neighbouring positions of a dense list
+      // would queue up on one LDS word.  A position costs one dword load, a
+      // shift, a mask and an add: the bit offset inside the byte is the same for
+      // all lanes and rounds (a thread's positions start 8 w bits = w bytes
+      // apart, rounds 256 w bytes), so shifts and the offsets of a thread's
+      // eight loads are scalars.  The partial last round goes first, through the
+      // general accessor.
+      const uint32_t w = RD::kKind == RK_PTR ? 32u : rd.w;
+      const uint32_t msk = RD::kKind == RK_PTR ? 0xFFFFFFFFu : (uint32_t)rd.mask;
+      const uint32_t n_full = cnt / ROUND, tail0 = n_full * ROUND;
+      const uint32_t k = (uint32_t)rd.base - tile_row0;  // value field + k = row relative to the tile
+      const uint64_t bit0 = (uint64_t)lo * w;            // wave uniform
+      const uint32_t sub = (uint32_t)bit0 & 7u;
+      const uint8_t* q0 = rd.p + (bit0 >> 3) + threadIdx.x * w;
+      const uint32_t rstride = (ROUND / 8) * w;          // bytes between rounds
+      uint32_t tv[PPT];
+      if (tail0 < cnt) {
+        const auto list = rd.view(lo);
 #pragma unroll
-      for (uint32_t u = 0; u < PPT; ++u) {
-        const uint32_t q = pos[u] - tile_row0;             // wraps for a position in front of the tile
-        if (i0 + u * kBlock < cnt && q < span) atomicOr(&bits32[q >> 5], 1u << (q & 31));
+        for (uint32_t u = 0; u < PPT; ++u) {
+          const uint32_t i = tail0 + threadIdx.x * PPT + u;
+          tv[u] = list.at(i < cnt ? i : cnt - 1);
+        }
       }
+      uint32_t cur[PPT], nxt[PPT];
+      auto issue = [&](uint32_t r, uint32_t (&raw)[PPT]) {
+        const uint8_t* q = q0 + (uint64_t)r * rstride;
 #pragma unroll
-      for (uint32_t u = 0; u < PPT; ++u) pos[u] = nxt[u];
+        for (uint32_t u = 0; u < PPT; ++u) raw[u] = ldu32(q + ((sub + u * w) >> 3));
+      };
+      if (n_full) issue(0, cur);
+      if (tail0 < cnt) {  // lanes past the list sit out
+#pragma unroll
+        for (uint32_t u = 0; u < PPT; ++u)
+          if (tail0 + threadIdx.x * PPT + u < cnt) set_row(tv[u] - tile_row0);
+      }
+      for (uint32_t r = 0; r < n_full; ++r) {  // workgroup uniform
+        if (r + 1 < n_full) issue(r + 1, nxt);
+#pragma unroll
+        for (uint32_t u = 0; u < PPT; ++u) set_row(((cur[u] >> ((sub + u * w) & 7u)) & msk) + k);
+#pragma unroll
+        for (uint32_t u = 0; u < PPT; ++u) cur[u] = nxt[u];
+      }
+    } else {
+      // wide or constant position fields (never written by the reference's encoder for row numbers): the general accessor
+      const auto list = rd.view(lo);
+      uint32_t pos[PPT], nxt[PPT];
+      auto fetch = [&](uint32_t (&dst)[PPT], uint32_t i0) {  // positions lo + i0 + u * kBlock
+#pragma unroll
+        for (uint32_t u = 0; u < PPT; ++u) {
+          const uint32_t i = i0 + u * kBlock;
+          dst[u] = list.at(i < cnt ? i : cnt - 1);
+        }
+      };
+      if (cnt) fetch(pos, threadIdx.x);
+      for (uint32_t r0 = 0; r0 < cnt; r0 += ROUND) {  // r0: workgroup uniform
+        if (r0 + ROUND < cnt) fetch(nxt, r0 + threadIdx.x + ROUND);
+#pragma unroll
+        for (uint32_t u = 0; u < PPT; ++u)
+          if (r0 + threadIdx.x + u * kBlock < cnt) set_row(pos[u] - tile_row0);
+#pragma unroll
+        for (uint32_t u = 0; u < PPT; ++u) pos[u] = nxt[u];
+      }
     }
   });
   NBL_PHASE(smem, kSmemBytes, 2);  // positions loaded and set
