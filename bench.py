@@ -63,6 +63,7 @@ def parse_args(argv=None):
     ap.add_argument("--event-every", type=int, default=4, help="record the per-launch HIP events on every N-th timed step")
     ap.add_argument("--no-breakdown", action="store_true", help="skip the per-operation profile of the unfused plan")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the short runs of the other benchmark tables")
+    ap.add_argument("--no-cold", action="store_true", help="skip the cold-cache steps (profiling runs: keeps the per-kernel averages to the timed loop)")
     ap.add_argument("--check", action="store_true", help="verify a sample of the output against the oracle")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for N>1 (nccl = RCCL; gloo only to rehearse several ranks on one GPU)")
@@ -614,7 +615,7 @@ def main():
         result.update(plan_fields(job, ms_per_step))
 
     solo = rank == 0 and n_gpus == 1 and len(job.plans) == 1
-    if solo:
+    if solo and not args.no_cold:
         cold_ms = cold_steps(job, torch, device, 5)
         job.status()
         result["cold_ms_per_step"] = round(cold_ms, 4)

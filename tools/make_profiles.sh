@@ -12,7 +12,7 @@ mkdir -p "$OUT" "$ROOT/profiles"
 cd /tmp && export TMPDIR=/tmp
 declare -A ROWS=([fbw_rle]=10000000 [dict_string]=10000000 [mixed]=1250000 [wide]=100000)
 for W in $WL; do
-  ARGS="--workload $W --no-cpu-baseline --no-pcie --no-breakdown --no-other-workloads"
+  ARGS="--workload $W --no-cpu-baseline --no-pcie --no-breakdown --no-other-workloads --no-cold"
   rm -rf "$OUT/$W"
   timeout -s KILL 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$W/stats" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/$W.stats.json" 2> "$OUT/$W.stats.err"
   cp "$(ls "$OUT/$W"/stats/*/*kernel_stats.csv | head -1)" "$ROOT/profiles/${TAG}_${W}_kernel_stats.csv"
