@@ -1319,14 +1319,20 @@ template <uint32_t W>
 __device__ __forceinline__ void sparse_bits_tile(const KArgs& a, const NodeDesc& nd, uint32_t tile, uint8_t* smem) {
   constexpr uint32_t WPT = W / kBlock;
   constexpr uint32_t TR = W * 64;  // rows per tile
-  static_assert(W % kBlock == 0 && W * 8 + 16 <= kScratchOff && kBlock == kBitTileWords, "sparse tile geometry");
-  uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem);           // W words, then one spare word: bit TR takes what falls outside the tile
-  uint32_t* s_k = reinterpret_cast<uint32_t*>(smem + W * 8 + 8);
+  static_assert(W % kBlock == 0 && (W + 1) * 8 + 16 + 4 * 64 + 16 <= kScratchOff && kBlock == kBitTileWords, "sparse tile geometry");
+  // LDS: the tile's nw <= W words, one spare word (its lowest bit takes what
+  // falls outside the tile), the waves' stages for packed positions; the
+  // tile's range of the list sits in front of the scratch bytes.
+  uint64_t* s_bits = reinterpret_cast<uint64_t*>(smem);
+  uint32_t* s_k = reinterpret_cast<uint32_t*>(smem + kScratchOff - 16);
   const uint64_t rows = nd.rows;
   const uint32_t K = nd.c0.rows;
   const uint64_t p0 = (uint64_t)tile * TR;
   const uint64_t p1 = p0 + TR < rows ? p0 + TR : rows;
   uint64_t* dst = reinterpret_cast<uint64_t*>(a.work + nd.self.off);
+  const uint32_t nw = (uint32_t)((p1 - p0 + 63) >> 6);  // words of this tile
+  const uint32_t stage0 = ((nw + 1) * 8 + 15) & ~15u;
+  uint32_t lo_ = 0, hi_ = 0;
   with_reader<4>(nd.c0, a, [&](auto rd) {
     // the node's first tile starts at position 0 and its last one ends with the
     // list: no search (a node of one tile does none at all)
@@ -1347,69 +1353,92 @@ __device__ __forceinline__ void sparse_bits_tile(const KArgs& a, const NodeDesc&
     __syncthreads();
     NBL_PHASE(smem, kSmemBytes, 1);  // descriptor, searches, zeroed tile
     const uint32_t lo = s_k[0], hi = s_k[1];
+    lo_ = lo;
+    hi_ = hi;
     uint32_t* bits32 = reinterpret_cast<uint32_t*>(s_bits);
-    // Dense columns are bound by the vector instructions per position, so the
-    // loop is pared down to them.  A listed row sets bit (row - first row of the
-    // tile); anything outside the tile -- the sentinel behind the last row, a
-    // position of damaged input -- is clamped onto the spare bit behind the
-    // tile's words instead of being tested for (a wrapped difference is large,
-    // so one unsigned minimum does both sides).  Eight positions per thread and
-    // round, the next round's loads issued before this round's are used: a
-    // column of R rounds waits for about one memory round trip instead of R.
+    // A listed row sets bit (row - first row of the tile); anything outside the
+    // tile -- the sentinel behind the last row, a position of damaged input --
+    // is clamped onto the spare bit behind the tile's words instead of being
+    // tested for (a wrapped difference is large, so one unsigned minimum does
+    // both sides).
     constexpr uint32_t PPT = 8, ROUND = PPT * kBlock;
     const uint32_t tile_row0 = (uint32_t)p0;
     const uint32_t cnt = hi > lo ? hi - lo : 0u;       // positions of this tile (<= its rows)
+    const uint32_t spare = nw * 64;
     auto set_row = [&](uint32_t rel) {
-      const uint32_t q = rel < TR ? rel : TR;
+      const uint32_t q = rel < spare ? rel : spare;
       atomicOr(&bits32[q >> 5], 1u << (q & 31));
     };
     using RD = decltype(rd);
-    constexpr bool kFast = RD::kKind == RK_FBW32 || RD::kKind == RK_PTR;
-    if constexpr (kFast) {
-      // A thread takes eight CONSECUTIVE positions of a round (2,048 positions),
-      // so the lanes of one instruction hold positions eight apart: their bits
-      // fall into different words, where neighbouring positions of a dense list
-      // would queue up on one LDS word.  A position costs one dword load, a
-      // shift, a mask and an add: the bit offset inside the byte is the same for
-      // all lanes and rounds (a thread's positions start 8 w bits = w bytes
-      // apart, rounds 256 w bytes), so shifts and the offsets of a thread's
-      // eight loads are scalars.  The partial last round goes first, through the
-      // general accessor.
-      const uint32_t w = RD::kKind == RK_PTR ? 32u : rd.w;
-      const uint32_t msk = RD::kKind == RK_PTR ? 0xFFFFFFFFu : (uint32_t)rd.mask;
-      const uint32_t n_full = cnt / ROUND, tail0 = n_full * ROUND;
+    if constexpr (RD::kKind == RK_FBW32) {
+      // Packed positions of up to 25 bits.  What bounds a dense list is the rate
+      // at which a CU takes vector memory instructions (a dword load per
+      // position, lanes a few bytes apart, runs at two positions per clock and
+      // CU), so the list comes in as 16-byte loads and is taken apart from LDS:
+      // a wave copies the bytes of its next `g` x 8 positions (at most 1 KiB)
+      // into a stage of its own behind the tile's words -- one load and one LDS
+      // store per lane and round, no workgroup barrier: the LDS operations of a
+      // wave complete in order -- and lane i < g takes the eight CONSECUTIVE
+      // positions that start 8 i w bits into it, each as two aligned dwords and
+      // a funnel shift (LDS reads at byte addresses run at a fifth of the rate).
+      // Consecutive positions per lane keep the lanes of one LDS atomic eight
+      // positions apart, i.e. on different words, where neighbouring positions
+      // of a dense list would queue up on one.  Two rounds of loads are in
+      // flight per wave.  What does not fill a wave's round goes through the
+      // general accessor, two positions per thread.
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      const uint32_t w = rd.w;
+      const uint32_t msk = (uint32_t)rd.mask;
       const uint32_t k = (uint32_t)rd.base - tile_row0;  // value field + k = row relative to the tile
       const uint64_t bit0 = (uint64_t)lo * w;            // wave uniform
       const uint32_t sub = (uint32_t)bit0 & 7u;
-      const uint8_t* q0 = rd.p + (bit0 >> 3) + threadIdx.x * w;
-      const uint32_t rstride = (ROUND / 8) * w;          // bytes between rounds
-      uint32_t tv[PPT];
+      const uint32_t room = ((kScratchOff - 16 - stage0) >> 2) & ~15u;  // bytes of LDS per wave
+      const uint32_t sb = room < 1056u ? room : 1056u;
+      const uint32_t lim = sb - 32 < 1023u ? sb - 32 : 1023u;  // a lane's 16 bytes times 64 lanes hold the round and one byte more
+      const uint32_t g = lim / w < 64u ? lim / w : 64u;         // lanes at work
+      const uint32_t P = g * 8, Bw = g * w;                      // positions and bytes of a wave's round
+      const uint32_t n_wr = cnt / P, tail0 = n_wr * P;
+      const uint32_t nl = (Bw + 16) >> 4;                        // lanes that load: Bw + 1 bytes
+      const uint32_t lane = lane_id(), wv = wave_id();
+      uint8_t* st = smem + stage0 + wv * sb;
+      uint32_t tv[2];
       if (tail0 < cnt) {
         const auto list = rd.view(lo);
 #pragma unroll
-        for (uint32_t u = 0; u < PPT; ++u) {
-          const uint32_t i = tail0 + threadIdx.x * PPT + u;
+        for (uint32_t u = 0; u < 2; ++u) {
+          const uint32_t i = tail0 + threadIdx.x * 2 + u;
           tv[u] = list.at(i < cnt ? i : cnt - 1);
         }
       }
-      uint32_t cur[PPT], nxt[PPT];
-      auto issue = [&](uint32_t r, uint32_t (&raw)[PPT]) {
-        const uint8_t* q = q0 + (uint64_t)r * rstride;
+      if (wv < n_wr) {
+        const uint8_t* g0 = rd.p + (bit0 >> 3) + lane * 16;
+        const uint32_t last = n_wr - 1;
+        auto ld = [&](uint32_t j) {
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (lane < nl) __builtin_memcpy(&v, g0 + (uint64_t)(j < last ? j : last) * Bw, 16);
+          return v;
+        };
+        u32x4 c0 = ld(wv), c1 = ld(wv + 4);
+        for (uint32_t j = wv; j < n_wr; j += 4) {  // wave uniform
+          const u32x4 c2 = ld(j + 8);
+          if (lane < nl) *reinterpret_cast<u32x4*>(st + lane * 16) = c0;
+          if (lane < g) {
+            const uint32_t b0 = sub + lane * 8 * w;  // bit offset of the lane's first position in the stage
 #pragma unroll
-        for (uint32_t u = 0; u < PPT; ++u) raw[u] = ldu32(q + ((sub + u * w) >> 3));
-      };
-      if (n_full) issue(0, cur);
-      if (tail0 < cnt) {  // lanes past the list sit out
-#pragma unroll
-        for (uint32_t u = 0; u < PPT; ++u)
-          if (tail0 + threadIdx.x * PPT + u < cnt) set_row(tv[u] - tile_row0);
+            for (uint32_t u = 0; u < 8; ++u) {
+              const uint32_t b = b0 + u * w;
+              const uint32_t* d = reinterpret_cast<const uint32_t*>(st + ((b >> 3) & ~3u));
+              set_row((__builtin_amdgcn_alignbit(d[1], d[0], b) & msk) + k);  // the shift takes the low five bits of b
+            }
+          }
+          c0 = c1;
+          c1 = c2;
+        }
       }
-      for (uint32_t r = 0; r < n_full; ++r) {  // workgroup uniform
-        if (r + 1 < n_full) issue(r + 1, nxt);
+      if (tail0 < cnt) {  // threads past the list sit out
 #pragma unroll
-        for (uint32_t u = 0; u < PPT; ++u) set_row(((cur[u] >> ((sub + u * w) & 7u)) & msk) + k);
-#pragma unroll
-        for (uint32_t u = 0; u < PPT; ++u) cur[u] = nxt[u];
+        for (uint32_t u = 0; u < 2; ++u)
+          if (tail0 + threadIdx.x * 2 + u < cnt) set_row(tv[u] - tile_row0);
       }
     } else {
       // wide or constant position fields (never written by the reference's encoder for row numbers): the general accessor
@@ -1467,7 +1496,7 @@ __device__ __forceinline__ void sparse_bits_tile(const KArgs& a, const NodeDesc&
     // tile itself -- its range of the list must have put that many distinct bits
     // into it (the sentinel behind the last row aside) -- so a list that is not
     // sorted raises the status bit instead of yielding ranks that do not add up.
-    const uint32_t lo = s_k[0], hi = s_k[1];
+    const uint32_t lo = lo_, hi = hi_;
     uint32_t* tmp = reinterpret_cast<uint32_t*>(smem);
     uint32_t* s_part = tmp + 4;
     const uint32_t sub = (uint32_t)(nd.aux2 >> 6);

@@ -40,8 +40,11 @@ def column(c):
     return (f"f{c}", E.nullable_wrap(data, mask, nulls, W.FLOAT))
 
 
-distinct = [column(c) for c in range(25)]
-buf, offs = workloads.pack_chunks([distinct[i % 25] for i in range(columns)])
+if kind == "wide":  # the benchmark table itself: read the bitmap step's records with PHASE_LAUNCH=<index of k_sparse_bits>
+    buf, offs = workloads.pack_chunks(workloads.wide_table_stripe(0, columns, rows))
+else:
+    distinct = [column(c) for c in range(25)]
+    buf, offs = workloads.pack_chunks([distinct[i % 25] for i in range(columns)])
 plan = Plan(buf, offs, per_kernel=True)
 dec = BatchDecoder(plan)
 dec.stage()
@@ -71,3 +74,6 @@ for i, n in enumerate(names):
     tot += c
     print(f"  {n:36s} {c:9.0f} cycles")
 print(f"  {'sum':36s} {tot:9.0f} cycles")
+life = rec.astype(np.float64).sum(axis=1)
+print(f"  tile lifetimes: sum {life.sum() / 2.4e3:.0f} us at 2.4 GHz = {life.sum() / 2.4e3 / 2048:.1f} us over 2,048 workgroup slots; longest {life.max() / 2.4e3:.1f} us; quartiles "
+      + " / ".join(f"{np.percentile(life, q) / 2.4e3:.1f}" for q in (25, 50, 75)) + " us")
