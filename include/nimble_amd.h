@@ -60,8 +60,9 @@ typedef struct nbl_options {
                                     * the level's fused launch); 0 = the library's default (32768, about
                                     * 0.5 GB of scattered output).  Read when struct_size >= 16.
                                     * No counterpart in the reference. */
-  uint32_t lds_dictionary_min_tiles; /* tiles of 8-byte dictionaries with 2,049 .. 4,096 entries in one cascade
-                                      * level from which the LDS-alphabet kernel gets a launch of its own (fewer
+  uint32_t lds_dictionary_min_tiles; /* tiles of 8-byte dictionaries with 2,049 .. 4,096 entries (short strings
+                                      * under bit-packed indices: up to 65,536) in one cascade level from which
+                                      * the kernel that keeps the alphabet in LDS gets a launch of its own (fewer
                                       * are gathered from memory inside the fused launch); 0 = the library's
                                       * default (4096).  Read when struct_size >= 20.  No counterpart in the
                                       * reference. */
@@ -85,7 +86,10 @@ typedef struct nbl_options {
 #define NBL_PLAN_FOUR_WAVE_SCATTER 4u
 /* Gather every dictionary from memory; by default dictionaries of 8-byte rows
  * (64-bit numbers, string views) with 2,049 .. 4,096 entries run on a kernel
- * that keeps the alphabet in LDS.  Same results; for tuning and tests. */
+ * that keeps the alphabet in LDS, and dictionaries of strings no longer than
+ * 255 bytes whose indices are bit-packed at up to 16 bits, with 2,049 ..
+ * 65,536 entries, on one that keeps the views in LDS in compact form.  Same
+ * results; for tuning and tests. */
 #define NBL_PLAN_NO_LDS_DICTIONARY 8u
 
 typedef struct nbl_plan nbl_plan;

@@ -58,6 +58,10 @@ enum KernelId : uint32_t {
   K_DICT_LDS,             // Dictionary of 8-byte rows (numbers, string views) whose alphabet fits kDictLdsEntries but not
                           // the fused launch's stage, alone or gathered inside a rank scatter (NF_DICT_VALUES): the
                           // alphabet sits in LDS and one workgroup runs kDictLdsTiles tiles against it
+  K_DICT_STR,             // Dictionary of strings no longer than kDictStrMaxLen bytes with up to kDictStrEntries entries,
+                          // alone or inside a rank scatter: the alphabet's views sit in LDS in compact form (a 16-bit
+                          // offset per entry, relative to a base per 256 entries: NodeDesc::aux3 names the table that
+                          // the alphabet's K_STRING_VIEWS step wrote) and one workgroup runs kDictStrTiles tiles
   K_COUNT,
   // Launch ids of the fused launches: one launch runs every step of a cascade
   // level, each tile naming its own operation (TileRef::tile, high byte).
@@ -76,15 +80,17 @@ constexpr uint32_t make_op(uint32_t kernel, uint32_t es) { return kernel * 4u + 
 constexpr bool kernel_has_es(uint32_t k) {
   return k == K_MATERIALIZE || k == K_MATERIALIZE_FBW || k == K_MATERIALIZE_RAW || k == K_RLE_EXPAND ||
          k == K_SELECT_SCATTER || k == K_DICT_GATHER || k == K_VARINT_DECODE || k == K_FRAME_UNPACK ||
-         k == K_SELECT_SCATTER_WAVE || k == K_DICT_LDS;
+         k == K_SELECT_SCATTER_WAVE || k == K_DICT_LDS || k == K_DICT_STR;
 }
 // Operations the fused level launch carries.  The block encodings are rare
 // (experimental in the reference) and their body would cost the fused kernel
 // registers it does not have to spare, so they keep a launch of their own.
 // The one-wave rank scatter is a launch of its own by construction: 64-thread
 // workgroups with a quarter of the LDS, so that a CU holds 32 of its tiles.
-// So is the LDS-alphabet dictionary kernel: 40 KiB of LDS per workgroup.
-constexpr bool kernel_is_fusable(uint32_t k) { return k != K_FRAME_UNPACK && k != K_SELECT_SCATTER_WAVE && k != K_DICT_LDS; }
+// So are the LDS-alphabet dictionary kernels: 40 KiB of LDS per workgroup, or most of a CU's for compact string views.
+constexpr bool kernel_is_fusable(uint32_t k) {
+  return k != K_FRAME_UNPACK && k != K_SELECT_SCATTER_WAVE && k != K_DICT_LDS && k != K_DICT_STR;
+}
 constexpr uint32_t op_of(uint32_t kernel, uint32_t es) { return make_op(kernel, kernel_has_es(kernel) ? es : 1u); }
 
 enum NodeFlags : uint32_t {
@@ -106,6 +112,8 @@ enum NodeFlags : uint32_t {
   NF_BOOL_BYTES = 1u << 10,  // K_RLE_EXPAND_BOOL: the node is a chunk's root: self = its values in out, one byte per row
   NF_WHOLE_NODE = 1u << 11,  // K_SPARSE_BITS / K_REDUCE_POPC: one workgroup holds the whole node (<= kWholeTileRows rows):
                              // no search for a tile's range of positions, no ticket and no look-back
+  NF_COMPACT_VIEWS = 1u << 12,  // K_STRING_VIEWS: also write the views in compact form (dict_str_table_bytes(rows) bytes at
+                                // work + aux_off) for a K_DICT_STR gather; every length is at most kDictStrMaxLen
   NF_FRAME_BITS = 1u << 4,   // K_FRAME_UNPACK: FOR (u64 bit offsets, no raw marker) instead of
                              // BlockBitPacking (u32 byte offsets, width 255 = raw block)
 };
@@ -140,7 +148,8 @@ struct NodeDesc {
   uint32_t n_parts;   // number of scan tiles
   uint32_t total_idx; // slot in the node-totals array: [total, flag word, ticket counter of the chained scan, spare]
   uint32_t look_base; // first look-back word of the node's chained scan (KArgs::look), one per scan tile
-  uint64_t aux3;       // NF_NESTED_SELECT: fill value of the inner selection (its common value)
+  uint64_t aux3;       // NF_NESTED_SELECT: fill value of the inner selection (its common value);
+                       // K_DICT_STR: the alphabet's compact table (work)
   uint32_t part_base2; // NF_NESTED_SELECT: first slot of the inner node's rank partials
   uint32_t total_idx2; // NF_NESTED_SELECT: the inner node's slot in the node-totals array
 };
@@ -192,5 +201,19 @@ constexpr uint32_t kWaveBlock = 64;
 constexpr uint32_t kDictLdsEntries = 4096;
 constexpr uint32_t kDictLdsTiles = 8;
 constexpr uint32_t kWaveStageBytes = 2432;
+// K_DICT_STR: string views {offset, length} whose strings lie back to back, as
+// K_STRING_VIEWS writes them, in compact form: per block of 256 entries the
+// offset of its first entry (uint32), then per entry its offset relative to
+// that (uint16) with one more slot per block for the end of its last entry:
+// entry i sits in slot i + i / 256, its length is the next slot minus its own.
+// Lengths of at most 255 bytes keep a block's span below 65,536.
+constexpr uint32_t kDictStrEntries = 65536;
+constexpr uint32_t kDictStrMaxLen = 255;
+constexpr uint32_t kDictStrTiles = 32;   // 16 KiB tiles one workgroup decodes against its copy of the table
+constexpr uint32_t dict_str_blocks(uint32_t entries) { return (entries + 255u) >> 8; }
+constexpr uint32_t dict_str_slots_off(uint32_t entries) { return (dict_str_blocks(entries) * 4u + 15u) & ~15u; }
+constexpr uint32_t dict_str_table_bytes(uint32_t entries) {
+  return dict_str_slots_off(entries) + (((entries + dict_str_blocks(entries)) * 2u + 4u + 15u) & ~15u);
+}
 
 }  // namespace nbl

@@ -2575,6 +2575,179 @@ __device__ __forceinline__ void body_dict_lds(const KArgs& a, const NodeDesc& nd
   if (bad) atomicOr(a.status, ST_DICT_INDEX_RANGE);
 }
 
+// ---------------------------------------------------------------- K_DICT_STR
+// The gather of K_DICT_LDS for string alphabets of up to kDictStrEntries entries:
+// what sits in LDS is not the 8-byte views but the compact table their
+// K_STRING_VIEWS step wrote beside them (two bytes per entry, layout in
+// nbl_desc.h), so 65,536 entries take 130 KiB instead of 512.  From memory every
+// row of such a column costs the vector L1 a 128-byte line fill (the alphabet
+// is far larger than the cache), which bounds the column at a third of the rate
+// its bytes could move at.  A view is put together from one pair of aligned
+// dwords (the entry's slot and the next one) and the base of its block.
+//
+// The table leaves room for one workgroup per CU, so that workgroup is sixteen
+// waves which, once the table is in place, never meet again: a wave owns two of
+// the group's kDictStrTiles tiles and works through them in slices of 512 rows
+// with LDS of its own (the tile's bitmap words and their rank prefixes, the
+// slice's packed indices), nothing but its own memory accesses to wait for, and
+// the loads of two slices ahead in flight.  Indices are bit-packed, 1 .. 16 bits
+// (the planner's condition): a slice's are at most 1 KiB, 16 bytes per lane.
+constexpr uint32_t kDictStrBlock = 1024, kDictStrWaves = kDictStrBlock / 64;
+constexpr uint32_t kDictStrSliceRows = 512;
+constexpr uint32_t kDictStrTableBytes = dict_str_table_bytes(kDictStrEntries);
+constexpr uint32_t kDictStrPartsBytes = ((kDictStrTiles + 1) * 4 + 15) & ~15u;
+constexpr uint32_t kDictStrWaveStage = kDictStrSliceRows * 2 + 32;                    // packed indices of a slice
+constexpr uint32_t kDictStrWaveBytes = kDictStrWaveStage + 64 * 8 + 68 * 4;           // + bitmap words and rank prefixes of the wave's two tiles
+constexpr uint32_t kDictStrSmemBytes = kDictStrTableBytes + kDictStrPartsBytes + kDictStrWaves * kDictStrWaveBytes;
+static_assert(kDictStrSmemBytes <= 160 * 1024 && kDictStrTableBytes % 16 == 0 && kDictStrWaveBytes % 16 == 0, "one workgroup per CU");
+static_assert(kDictStrTiles == 2 * kDictStrWaves && kTileBytes / 8 == 4 * kDictStrSliceRows, "two tiles per wave, four slices per tile");
+
+__device__ __forceinline__ void body_dict_str(const KArgs& a, const NodeDesc& nd, uint32_t group, uint8_t* smem, uint32_t pslot0) {
+  using T = uint64_t;
+  constexpr int ES = 8;
+  constexpr uint32_t TE = kTileBytes / ES, W = TE / 64;  // 2,048 rows, 32 bitmap words per tile
+  const bool scatter = (nd.flags & NF_DICT_VALUES) != 0;
+  const ColRef& aref = scatter ? nd.c0 : nd.c1;
+  const ColRef& iref = scatter ? nd.c1 : nd.c0;
+  const uint32_t A = aref.rows;  // 1 .. kDictStrEntries: the planner's choice
+  const uint64_t rows = nd.rows;
+  const uint32_t n_tiles = (uint32_t)((rows + TE - 1) / TE);
+  const uint32_t t_begin = group * kDictStrTiles;
+  const uint32_t n_t = (t_begin + kDictStrTiles < n_tiles ? t_begin + kDictStrTiles : n_tiles) - t_begin;  // 1 .. 32
+  const bool invert = (nd.flags & NF_INVERT_SEL) != 0;
+  const uint32_t nvals = iref.rows;
+  const T fill = (T)nd.aux;
+  const uint32_t lane = lane_id(), wv = wave_id();
+  uint32_t* s_parts = reinterpret_cast<uint32_t*>(smem + kDictStrTableBytes);
+  if (scatter && group == 0 && threadIdx.x == 0 && sload32(a.totals + nd.total_idx) != nvals) atomicOr(a.status, ST_SELECT_COUNT);
+  {  // the table: a straight copy, eight loads of a thread in flight together
+    const u32x4* src = reinterpret_cast<const u32x4*>(a.work + nd.aux3);
+    u32x4* dst = reinterpret_cast<u32x4*>(smem);
+    const uint32_t nvec = dict_str_table_bytes(A) >> 4;
+    constexpr uint32_t U = 8;
+    for (uint32_t v0 = 0; v0 < nvec; v0 += U * kDictStrBlock) {  // workgroup uniform
+      u32x4 q[U];
+#pragma unroll
+      for (uint32_t u = 0; u < U; ++u) {
+        const uint32_t i = v0 + u * kDictStrBlock + threadIdx.x;
+        q[u] = src[i < nvec ? i : nvec - 1];
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < U; ++u) {
+        const uint32_t i = v0 + u * kDictStrBlock + threadIdx.x;
+        if (i < nvec) dst[i] = q[u];
+      }
+    }
+    // the group's rank partials, one per tile (the node's total sits behind its last one)
+    if (scatter && threadIdx.x < n_t) s_parts[threadIdx.x] = a.parts[pslot0 + threadIdx.x];
+  }
+  __syncthreads();  // the only one
+  const uint32_t* s_coarse = reinterpret_cast<const uint32_t*>(smem);
+  const uint32_t* s_slots = reinterpret_cast<const uint32_t*>(smem + dict_str_slots_off(A));  // two 16-bit slots per dword
+  auto view_of = [&](uint32_t i) -> T {
+    const uint32_t k = i + (i >> 8);
+    const uint32_t pair = __builtin_amdgcn_alignbit(s_slots[(k >> 1) + 1], s_slots[k >> 1], (k & 1u) * 16u);  // slots k, k + 1
+    const uint32_t lo = pair & 0xFFFFu;
+    return (T)(s_coarse[i >> 8] + lo) | ((T)((pair >> 16) - lo) << 32);
+  };
+  // ---- from here on every wave is on its own
+  uint8_t* mine = smem + kDictStrTableBytes + kDictStrPartsBytes + wv * kDictStrWaveBytes;
+  const uint32_t* s_stage = reinterpret_cast<const uint32_t*>(mine);
+  uint64_t* s_words = reinterpret_cast<uint64_t*>(mine + kDictStrWaveStage);  // words of tile wv (0 .. 31) and of tile wv + 16 (32 .. 63)
+  uint32_t* s_pref = reinterpret_cast<uint32_t*>(mine + kDictStrWaveStage + 64 * 8);  // rank of each word's first row; [64], [65]: ranks behind the tiles
+  {
+    const uint32_t half = lane >> 5, tl = wv + kDictStrWaves * half;
+    const uint32_t t = t_begin + tl;
+    const uint64_t w = (uint64_t)t * W + (lane & 31u);
+    const bool live = tl < n_t && w * 64 < rows;
+    uint64_t word = 0;
+    if (live) {
+      if (scatter) word = BitsReader(nd.sel, a, invert).word(w);
+      else word = w * 64 + 64 > rows ? wmask((uint32_t)(rows - w * 64)) : ~0ull;  // every row takes the index of its own number
+      if (scatter && (nd.flags & NF_WRITE_NULLS))
+        reinterpret_cast<uint64_t*>(a.out + nd.aux_off)[w] = invert ? ~word & (w * 64 + 64 > rows ? wmask((uint32_t)(rows - w * 64)) : ~0ull) : word;
+    }
+    const uint32_t pc = (uint32_t)__popcll(word);
+    const uint32_t incl = wave_incl_scan(pc);
+    const uint32_t low = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);  // rows selected in the first of the two tiles
+    uint32_t first = 0;  // rank of the tile's first row
+    if (tl < n_t) first = scatter ? s_parts[tl] : t * TE;
+    const uint32_t excl = first + incl - pc - (half ? low : 0u);
+    s_words[lane] = word;
+    s_pref[lane] = excl;
+    if ((lane & 31u) == 31u) s_pref[64 + half] = excl + pc;
+  }
+  __builtin_amdgcn_wave_barrier();  // (the LDS operations of a wave complete in order; this keeps the compiler from moving them)
+  const uint8_t* ibase = a.arena + iref.off;
+  const uint32_t iw = iref.width, imask = (1u << iw) - 1u, ibias = (uint32_t)iref.base;
+  const uint32_t amax = A - 1;
+  bool bad = false;
+  struct Slice {
+    uint32_t rb, cnt, sub;  // first rank, ranks (clamped to what the index column holds), bit offset of the first index in its byte
+  };
+  auto slice_of = [&](uint32_t sl) {  // sl = 0 .. 7: four slices of the wave's first tile, then of its second
+    Slice x{0, 0, 0};
+    const uint32_t half = sl >> 2, m = sl & 3u;
+    if (sl < 8 && wv + kDictStrWaves * half < n_t) {
+      const uint32_t rb = s_pref[half * 32 + m * 8];
+      const uint32_t re = m == 3 ? s_pref[64 + half] : s_pref[half * 32 + m * 8 + 8];
+      const uint32_t avail = rb < nvals ? nvals - rb : 0u;  // ranks that disagree with the index column are clamped, never followed
+      x.rb = rb;
+      x.cnt = re - rb < avail ? re - rb : avail;
+      x.sub = (uint32_t)(((uint64_t)rb * iw) & 7u);
+    }
+    return x;
+  };
+  auto issue = [&](const Slice& x) {  // the slice's packed indices, 16 bytes per lane
+    u32x4 q = {0u, 0u, 0u, 0u};
+    const uint32_t bytes = x.cnt ? (x.cnt * iw + x.sub + 7u) >> 3 : 0u;  // <= 1,024; the arena's slop covers the last vector's overhang
+    if (lane * 16 < bytes) __builtin_memcpy(&q, ibase + (((uint64_t)x.rb * iw) >> 3) + lane * 16, 16);
+    return q;
+  };
+  Slice x0 = slice_of(0), x1 = slice_of(1);
+  u32x4 q0 = issue(x0), q1 = issue(x1);
+  for (uint32_t sl = 0; sl < 8; ++sl) {  // wave uniform
+    const uint32_t half = sl >> 2, m = sl & 3u, tl = wv + kDictStrWaves * half;
+    if (tl >= n_t) break;
+    const Slice x2 = slice_of(sl + 2);
+    const u32x4 q2 = issue(x2);
+    __builtin_amdgcn_wave_barrier();
+    *reinterpret_cast<u32x4*>(mine + lane * 16) = q0;
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t t = t_begin + tl;
+    const uint64_t p0 = (uint64_t)t * TE;
+    const uint32_t tile_rows = rows - p0 < TE ? (uint32_t)(rows - p0) : TE;
+    T* dst = reinterpret_cast<T*>(self_ptr(nd, a)) + p0;
+    const uint32_t last = x0.cnt ? x0.cnt - 1 : 0u;
+#pragma unroll
+    for (uint32_t it = 0; it < 4; ++it) {
+      const uint32_t r = m * kDictStrSliceRows + it * 128 + lane * 2;  // row of the tile; r + 1 shares its bitmap word
+      const uint32_t wi = half * 32 + (r >> 6), bit = r & 63u;
+      const uint64_t wd = s_words[wi];
+      uint32_t sel = (uint32_t)(wd >> bit) & 3u;
+      const uint32_t k0 = s_pref[wi] + (uint32_t)__popcll(wd & ((1ull << bit) - 1ull)) - x0.rb;  // index of row r among the slice's, if selected
+      if (x0.cnt == 0) sel = 0;  // nothing staged: every row takes the fill
+      Vec16<ES> o;
+#pragma unroll
+      for (uint32_t j = 0; j < 2; ++j) {
+        const uint32_t k = k0 + (j ? sel & 1u : 0u);
+        const uint32_t b = x0.sub + (k < last ? k : last) * iw;
+        const uint32_t* d = s_stage + (b >> 5);
+        uint32_t i = (__builtin_amdgcn_alignbit(d[1], d[0], b) & imask) + ibias;
+        if (i > amax) {
+          bad |= ((sel >> j) & 1u) != 0 && r + j < tile_rows;
+          i = amax;
+        }
+        o.v[j] = pick<T>(sel, j, view_of(i), fill);
+      }
+      store_vec_padded<ES>(dst, r, tile_rows, o);
+    }
+    x0 = x1; x1 = x2;
+    q0 = q1; q1 = q2;
+  }
+  if (bad) atomicOr(a.status, ST_DICT_INDEX_RANGE);
+}
+
 // ----------------------------------------------------------- K_VARINT_DECODE
 // VarintEncoding::materialize (encodings/VarintEncoding.h:119-140): LEB128,
 // low 7 bits first, + baseline (common/Varint.h:83-143 for the byte limits).
@@ -2709,6 +2882,25 @@ __device__ __forceinline__ void body_string_views(const KArgs& a, const NodeDesc
   }
   // the last tile knows the sum of all lengths
   if (tile + 1 == n_tiles && threadIdx.x == 0 && (uint64_t)before + total > nd.aux2) atomicOr(a.status, ST_STRING_BYTES);
+  if (nd.flags & NF_COMPACT_VIEWS) {
+    // The same views in the compact form a K_DICT_STR gather keeps in LDS (layout:
+    // nbl_desc.h).  A thread's eight entries lie in one block of 256, which is the
+    // entries of 32 consecutive threads: the block's base is the offset of the
+    // first of them.
+    const uint32_t base = (uint32_t)__shfl((int)(uint32_t)v[0], (int)(lane_id() & 32u));
+    uint8_t* table = a.work + nd.aux_off;
+    uint32_t* coarse = reinterpret_cast<uint32_t*>(table);
+    uint16_t* slots = reinterpret_cast<uint16_t*>(table + dict_str_slots_off((uint32_t)n));
+    if (e0 < n) {
+      const uint32_t k0 = (uint32_t)e0 + (uint32_t)(e0 >> 8);
+#pragma unroll
+      for (uint32_t j = 0; j < 8; ++j)
+        if (e0 + j < n) slots[k0 + j] = (uint16_t)((uint32_t)v[j] - base);
+      // the slot behind a block's last entry holds where that entry ends (`off` by now)
+      if ((threadIdx.x & 31u) == 31u || e0 + 8 >= n) slots[k0 + (e0 + 8 <= n ? 8u : (uint32_t)(n - e0))] = (uint16_t)(off - base);
+      if ((threadIdx.x & 31u) == 0) coarse[e0 >> 8] = base;
+    }
+  }
 }
 
 // -------------------------------------------------------------- K_COPY_BYTES
@@ -3060,6 +3252,15 @@ __global__ __launch_bounds__(kBlock, 3) void k_dict_lds(KArgs a) {
   body_dict_lds(a, nd, group, smem, aux);
 }
 
+__global__ __launch_bounds__(kDictStrBlock, 1) void k_dict_str(KArgs a) {
+  __shared__ __align__(16) uint8_t smem[kDictStrSmemBytes];
+  const uint32_t node = sload32(&a.tiles[blockIdx.x].node);
+  const uint32_t group = sload32(&a.tiles[blockIdx.x].tile) & kTileMask;
+  const uint32_t aux = sload32(a.tile_aux + blockIdx.x);
+  const NodeDesc nd = load_node(a.nodes + node);
+  body_dict_str(a, nd, group, smem, aux);
+}
+
 template <bool LAST>
 __global__ __launch_bounds__(256, 8) void k_level(KArgs) {
   __shared__ __align__(16) uint8_t smem[kSmemBytes + kPhaseBytes];
@@ -3159,6 +3360,10 @@ extern "C" int nbl_launch_kernel(uint32_t kernel, uint32_t es, const nbl::KArgs*
     case K_DICT_LDS:
       if (es != 8) return -1;
       hipLaunchKernelGGL(k_dict_lds, grid, block, 0, s, a);
+      break;
+    case K_DICT_STR:
+      if (es != 8) return -1;
+      hipLaunchKernelGGL(k_dict_str, grid, dim3(kDictStrBlock), 0, s, a);
       break;
     default: return -1;
   }

@@ -95,6 +95,13 @@ struct PNode {
   // then names the uint32 indices and `alpha_ref` the alphabet element array
   bool fused_gather = false;
   ColRef alpha_ref{};
+  // Trivial<string>: the longest string its lengths child can hold (from the header: baseline + all bits set) and the
+  // descriptor of its lengths -> views step; Dictionary over such an alphabet, short strings, 4,097 .. 65,536 entries:
+  // `alpha_table` names the compact table that step also writes (K_DICT_STR)
+  uint64_t max_len = ~0ull;
+  int views_dn = -1;
+  bool alpha_compact = false;
+  uint64_t alpha_table = 0;
   // MainlyConstant whose scatter its Nullable / MainlyConstant parent performs
   // together with its own (NF_NESTED_SELECT): `ref` then names the other values,
   // `sel_ref` the isCommon bitmap, and the rank partials stay this node's
@@ -125,6 +132,7 @@ enum : uint8_t {
   DM_PARTS2 = 16,    // part_base2
   DM_TOTALS2 = 32,   // total_idx2
   DM_LOOK = 64,      // look_base
+  DM_AUX3_WORK = 128,  // aux3 is an offset into work (compact string views)
 };
 enum : uint8_t { LM_NULLS = 1, LM_STRING = 2, LM_DICT_ALPHABET = 4, LM_DICT_INDICES = 8 };
 
@@ -179,7 +187,7 @@ struct Launch {
 const char* kKernelNames[K_COUNT] = {
     "k_materialize", "k_bits_to_bytes", "k_reduce_popc", "k_rle_ends", "k_rle_expand", "k_rle_expand_bool", "k_sparse_bits",
     "k_select_scatter", "k_dict_gather", "k_varint_decode", "k_string_views", "k_copy_bytes",
-    "k_select_bits", "k_materialize_fbw", "k_materialize_raw", "k_frame_unpack", "k_select_scatter_wave", "k_dict_lds"};
+    "k_select_bits", "k_materialize_fbw", "k_materialize_raw", "k_frame_unpack", "k_select_scatter_wave", "k_dict_lds", "k_dict_str"};
 
 }  // namespace
 
@@ -203,7 +211,7 @@ struct nbl_plan {
   bool keep_dictionary = false;  // also emit alphabet + indices of dictionary chunks
   bool fused = true;          // one launch per cascade level (default) or one per (level, kernel, element size)
   bool wave_scatter = true;   // sparse rank scatters on the one-wave kernel (default) or every one on the four-wave tile
-  bool lds_dictionary = true; // 8-byte dictionaries of 2,049 .. 4,096 entries on the LDS-alphabet kernel (default) or gathered from memory
+  bool lds_dictionary = true; // 8-byte dictionaries on the kernels that keep the alphabet in LDS (default: K_DICT_LDS, K_DICT_STR) or gathered from memory
   uint64_t lds_dict_min_tiles = kLdsDictMinTiles;  // tiles of such dictionaries in one level that make a launch of that kernel
   uint64_t wave_min_tiles = kWaveLaunchMinTiles;  // tiles of one level and element size that make a one-wave launch
   int cur_chunk = -1;         // chunk being planned
@@ -671,6 +679,9 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
         const uint32_t dn = add_dnode(d, sm);
         add_step(lvl, K_STRING_VIEWS, 8, dn, nt);
         nn.ref = d.self; nn.ready = lvl + 1;
+        nn.views_dn = (int)dn;
+        if (d.c0.kind == COL_CONST) nn.max_len = (uint32_t)d.c0.base;
+        else if (d.c0.kind == COL_FBW && d.c0.width < 32) nn.max_len = (uint64_t)(uint32_t)d.c0.base + ((1ull << d.c0.width) - 1);
       } else if (nn.is_bool) {
         ColRef r{}; r.kind = COL_BITS_RAW; r.off = nn.payload_off; r.rows = rows;
         nn.ref = r; nn.ready = 0;
@@ -804,6 +815,22 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
           lvl = std::max(lvl, C(0).ready + 1);
         }
       }
+      // A string alphabet too large for the 8-byte views to sit in LDS, made of
+      // short strings: its lengths -> views step also writes the views in compact
+      // form, which a K_DICT_STR gather keeps in LDS instead.
+      if (lds_dictionary && es == 8 && C(0).is_string && C(0).enc == ET_TRIVIAL && C(0).views_dn >= 0 &&
+          C(0).max_len <= kDictStrMaxLen && C(0).rows > kTileBytes / 8 && C(0).rows <= kDictStrEntries &&
+          d.c0.kind == COL_FBW && d.c0.width >= 1 && d.c0.width <= 16) {  // the kernel takes bit-packed indices of up to 16 bits
+        const size_t vn = (size_t)C(0).views_dn;
+        if (!(dnodes[vn].flags & NF_COMPACT_VIEWS)) {
+          const uint64_t table = alloc_work(dict_str_table_bytes(C(0).rows));
+          dnodes[vn].flags |= NF_COMPACT_VIEWS;
+          dnodes[vn].aux_off = table;
+          dn_mask[vn] |= DM_AUX_WORK;
+        }
+        nn.alpha_compact = true;
+        nn.alpha_table = dnodes[vn].aux_off;
+      }
       if (nn.fused_gather) {
         nn.ref = d.c0; nn.ref.rows = rows;
         nn.alpha_ref = d.c1; nn.alpha_ref.rows = C(0).rows;
@@ -812,11 +839,14 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       }
       d.self = mat_ref(es);
       d.rows = rows;
-      const uint32_t dn = add_dnode(d);
+      if (nn.alpha_compact) d.aux3 = nn.alpha_table;
+      const uint32_t dn = add_dnode(d, nn.alpha_compact ? DM_AUX3_WORK : 0);
       // 8-byte rows over an alphabet that the fused launch cannot stage (more than
       // kTileBytes of entries) but kDictLdsEntries hold: the LDS-alphabet kernel,
       // one workgroup per kDictLdsTiles tiles
-      if (lds_dictionary && es == 8 && C(0).rows > kTileBytes / 8 && C(0).rows <= kDictLdsEntries)
+      if (nn.alpha_compact)
+        add_step(lvl, K_DICT_STR, es, dn, div_up32(div_up32(rows, tile_rows), kDictStrTiles));
+      else if (lds_dictionary && es == 8 && C(0).rows > kTileBytes / 8 && C(0).rows <= kDictLdsEntries)
         add_step(lvl, K_DICT_LDS, es, dn, div_up32(div_up32(rows, tile_rows), kDictLdsTiles));
       else
         add_step(lvl, K_DICT_GATHER, es, dn, div_up32(rows, tile_rows));
@@ -835,6 +865,7 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
         d.c0 = vals.alpha_ref;
         d.c1.rows = vals.rows;
         d.flags |= NF_DICT_VALUES;
+        if (vals.alpha_compact) d.aux3 = vals.alpha_table;
       }
       if (!nullable) {
         d.flags |= NF_INVERT_SEL;
@@ -879,6 +910,8 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       if (d.flags & NF_WRITE_NULLS) sm |= DM_AUX_OUT;
       if (d.flags & NF_NESTED_SELECT) sm |= DM_PARTS2 | DM_TOTALS2;
       if (d.flags & NF_RLE_VALUES) sm |= DM_TOTALS2;
+      const bool str_dict = (d.flags & NF_DICT_VALUES) && es == 8 && (nullable ? C(0) : C(1)).alpha_compact;
+      if (str_dict) sm |= DM_AUX3_WORK;
       if (counted) {
         dn_mask[(size_t)selc.sparse_dn] |= DM_PARTS | DM_TOTALS;
         NodeDesc& sd = dnodes[(size_t)selc.sparse_dn];
@@ -923,6 +956,7 @@ void nbl_plan::place(int idx, bool root, const ColRef* root_dst) {
       if (!nn.is_bool && (d.self.off % 16 != 0 || kAlign % 16 != 0)) fail(NBL_ERR_ARGUMENT, "rank-scatter destination is not a column of its own");
       const bool lds_dict = lds_dictionary && (d.flags & NF_DICT_VALUES) && es == 8 && d.c0.rows > kTileBytes / 8 && d.c0.rows <= kDictLdsEntries;
       if (nn.is_bool) add_step(fin, K_SELECT_BITS, 0, dn, nt);
+      else if (str_dict) add_step(fin, K_DICT_STR, es, dn, div_up32(nt, kDictStrTiles));
       else if (lds_dict) add_step(fin, K_DICT_LDS, es, dn, div_up32(nt, kDictLdsTiles));
       else add_step(fin, one_wave ? K_SELECT_SCATTER_WAVE : K_SELECT_SCATTER, es, dn, nt);
       nn.ref = d.self; nn.ready = fin + 1;
@@ -1070,6 +1104,7 @@ void nbl_plan::copy_from(const nbl_plan& sub, const MergeBase& b) {
     if (m & DM_LOOK) d.look_base += b.look;
     if (m & DM_PARTS2) d.part_base2 += b.parts;
     if (m & DM_TOTALS2) d.total_idx2 += b.totals;
+    if (m & DM_AUX3_WORK) d.aux3 += b.work;
     dnodes[b.dnode + i] = d;
     dn_mask[b.dnode + i] = m;
   }
@@ -1232,12 +1267,14 @@ void nbl_plan::finish() {
     // costs its ramp and tail and what its tiles would have hidden inside the
     // fused launch: below lds_dict_min_tiles tiles of a level the nodes keep the
     // fused launch's gather.
-    std::vector<uint64_t> lds_tiles((size_t)last_level + 1, 0);
+    // The same holds for the compact-views kernel, counted by itself.
+    std::vector<uint64_t> lds_tiles((size_t)(last_level + 1) * 2, 0);
     auto tiles_of = [&](const Step& st) { return (uint64_t)div_up32(dnodes[st.dnode].rows, kTileBytes / 8); };
+    auto slot_of = [&](const Step& st) { return (size_t)st.level * 2 + (st.kernel == K_DICT_STR ? 1u : 0u); };
     for (const Step& st : steps)
-      if (st.kernel == K_DICT_LDS) lds_tiles[(size_t)st.level] += tiles_of(st);
+      if (st.kernel == K_DICT_LDS || st.kernel == K_DICT_STR) lds_tiles[slot_of(st)] += tiles_of(st);
     for (Step& st : steps)
-      if (st.kernel == K_DICT_LDS && lds_tiles[(size_t)st.level] < lds_dict_min_tiles) {
+      if ((st.kernel == K_DICT_LDS || st.kernel == K_DICT_STR) && lds_tiles[slot_of(st)] < lds_dict_min_tiles) {
         st.kernel = (dnodes[st.dnode].flags & NF_DICT_VALUES) ? K_SELECT_SCATTER : K_DICT_GATHER;
         st.n_tiles = (uint32_t)tiles_of(st);
       }
@@ -1315,7 +1352,7 @@ void nbl_plan::finish() {
     while (j < steps.size() && steps[j].level == steps[i].level &&
            (fuse ? kernel_is_fusable(steps[j].kernel) : (steps[j].kernel == steps[i].kernel && steps[j].es == steps[i].es))) {
       const uint32_t op = op_of(steps[j].kernel, steps[j].es) << kOpShift;
-      const bool lds_dict = steps[j].kernel == K_DICT_LDS;  // an entry is a group of kDictLdsTiles tiles
+      const bool lds_dict = steps[j].kernel == K_DICT_LDS || steps[j].kernel == K_DICT_STR;  // an entry is a group of tiles
       const bool scatter = steps[j].kernel == K_SELECT_SCATTER || steps[j].kernel == K_SELECT_SCATTER_WAVE ||
                            (lds_dict && (dnodes[steps[j].dnode].flags & NF_DICT_VALUES));
       const uint32_t aux_base = scatter ? dnodes[steps[j].dnode].part_base : 0u;
@@ -1324,7 +1361,7 @@ void nbl_plan::finish() {
         TileRef* tr = tiles.data() + n_filled;
         uint32_t* ax = tile_aux.data() + n_filled;
         const uint32_t dn = steps[j].dnode, t0 = steps[j].tile_begin, nt = steps[j].n_tiles;
-        const uint32_t per = lds_dict ? kDictLdsTiles : 1u;
+        const uint32_t per = steps[j].kernel == K_DICT_LDS ? kDictLdsTiles : steps[j].kernel == K_DICT_STR ? kDictStrTiles : 1u;
         for (uint32_t t = 0; t < nt; ++t) tr[t] = TileRef{dn, op | (t0 + t)};
         for (uint32_t t = 0; t < nt; ++t) ax[t] = scatter ? aux_base + (t0 + t) * per : 0u;
         n_filled += nt;
@@ -1386,7 +1423,9 @@ void nbl_plan::finish() {
       if (r->kind == COL_MAT_WORK || r->kind == COL_BITS_WORK) r->off += scratch_base;
   }
   for (size_t i = 0; i < dnodes.size(); ++i)
-    if (dn_mask[i] & DM_AUX_WORK) dnodes[i].aux_off += scratch_base;  // run-end arrays
+    if (dn_mask[i] & DM_AUX_WORK) dnodes[i].aux_off += scratch_base;  // run-end arrays, compact string views
+  for (size_t i = 0; i < dnodes.size(); ++i)
+    if (dn_mask[i] & DM_AUX3_WORK) dnodes[i].aux3 += scratch_base;
   work_bytes = scratch_base + cur_work + kAlign;
   out_bytes = cur_out + kAlign;  // slack: staged 16-byte loads may run a few bytes past a column
   clock.mark("layout");

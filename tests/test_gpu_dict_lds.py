@@ -3,7 +3,9 @@ alphabet is held changes (DictionaryEncoding::materialize,
 encodings/DictionaryEncoding.h:193-236): up to 2,048 entries it is staged by
 the fused launch, 2,049 .. 4,096 entries run on the kernel that keeps the
 alphabet in LDS (one workgroup per eight 2,048-row tiles), more are gathered
-from memory.  Numbers and strings; alone, under a Nullable (bitmap and
+from memory -- except alphabets of strings no longer than 255 bytes under
+bit-packed indices of up to 16 bits, which from 2,049 to 65,536 entries run
+on the kernel that keeps their views in LDS in compact form.  Numbers and strings; alone, under a Nullable (bitmap and
 SparseBool nulls) and under a MainlyConstant.  check_parity also decodes every
 batch with the LDS kernel switched off."""
 import struct
@@ -46,8 +48,12 @@ def _alphabet(rng, A):
 
 
 def _dict_str(rng, alpha, n, index_spec=None):
+    """n rows over `alpha`; every entry is used when n allows it (the encoder drops unused ones)."""
     spec = E.Dictionary(alphabet=E.Trivial(lengths=E.FixedBitWidth()), indices=index_spec or E.FixedBitWidth())
-    return E.encode_dictionary_from_indices(spec, alpha, rng.integers(0, len(alpha), n), W.STRING)
+    idx = rng.integers(0, len(alpha), n)
+    if n >= len(alpha):
+        idx[rng.permutation(n)[: len(alpha)]] = np.arange(len(alpha))
+    return E.encode_dictionary_from_indices(spec, alpha, idx, W.STRING)
 
 
 def test_numeric_dictionaries_at_the_size_boundaries(gpu, oracle):
@@ -75,7 +81,11 @@ def test_string_dictionaries_at_the_size_boundaries(gpu, oracle):
             labels.append(f"strings alphabet {A} rows {n}")
         encs.append(_dict_str(rng, alpha, 30_000, E.Trivial()))  # indices as plain uint32
         labels.append(f"strings alphabet {A}, raw indices")
-    assert "k_dict_lds<8>" in _names(encs[labels.index("strings alphabet 4096 rows 50001")])
+    # short strings with bit-packed indices take the compact-views kernel from 2,049 entries on (below);
+    # raw uint32 indices keep these columns on the kernel that holds the 8-byte views
+    assert "k_dict_str<8>" in _names(encs[labels.index("strings alphabet 4096 rows 50001")])
+    assert "k_dict_lds<8>" in _names(encs[labels.index("strings alphabet 4096, raw indices")])
+    assert "k_dict_str<8>" not in _names(encs[labels.index("strings alphabet 2048 rows 50001")])
     check_parity(oracle, encs, labels=labels)
 
 
@@ -97,6 +107,8 @@ def test_dictionaries_gathered_inside_a_rank_scatter(gpu, oracle):
                 encs.append(E.nullable_wrap(data, mask, nulls, W.INT64))
                 labels.append(f"nullable int64 alphabet {A} rows {n} non-null {frac}")
     names = _names(encs[labels.index("nullable strings alphabet 4096 rows 70000 non-null 0.5")])
+    assert "k_dict_str<8>" in names and not any(k.startswith("k_select_scatter") for k in names)
+    names = _names(encs[labels.index("nullable int64 alphabet 4096 rows 70000 non-null 0.5")])
     assert "k_dict_lds<8>" in names and not any(k.startswith("k_select_scatter") for k in names)
     # MainlyConstant whose other values are a dictionary
     n = 60_000
@@ -134,3 +146,81 @@ def test_index_out_of_range_is_reported_by_the_lds_kernel(gpu):
         assert ei.value.status == capi.NBL_ERR_DEVICE_DATA
         dec.fetch()
         plan.close()
+
+
+# ---- string alphabets of 2,049 .. 65,536 short entries, bit-packed indices: the compact-views kernel (k_dict_str)
+
+STR_SIZES = (2049, 4097, 5000, 65_536)
+STR_ROWS = (1, 2047, 65_536, 65_537, 150_001)  # one group of 32 tiles, one row more, several groups
+
+
+def test_string_dictionaries_with_compact_views(gpu, oracle):
+    rng = np.random.default_rng(75)
+    encs, labels = [], []
+    for A in STR_SIZES + (65_537,):
+        alpha = _alphabet(rng, A)
+        for n in STR_ROWS:
+            encs.append(_dict_str(rng, alpha, n))
+            labels.append(f"strings alphabet {A} rows {n}")
+        encs.append(_dict_str(rng, alpha, 70_000, E.Trivial()))  # indices as plain uint32
+        labels.append(f"strings alphabet {A}, raw indices")
+    for A in STR_SIZES:
+        assert "k_dict_str<8>" in _names(encs[labels.index(f"strings alphabet {A} rows 150001")]), A
+    assert "k_dict_str<8>" not in _names(encs[labels.index("strings alphabet 65537 rows 150001")])
+    check_parity(oracle, encs, labels=labels)
+
+
+def test_compact_views_at_the_length_limit(gpu, oracle):
+    """Strings of up to 255 bytes keep a block of 256 entries within 16 bits; one
+    longer string and the column is gathered from memory."""
+    rng = np.random.default_rng(76)
+    A, n = 4400, 70_000
+    def column(lengths):  # distinct strings of exactly these lengths (4 bytes or more, or empty)
+        items = [bytes(rng.integers(0, 256, int(l) - 4, dtype=np.uint8)) + struct.pack("<I", i) if l else b"" for i, l in enumerate(lengths)]
+        return E.StringColumn.from_list(items)
+    full = column(np.r_[np.full(A - 1, 255), 0])            # 255 bytes each: blocks of 256 entries span 65,280 bytes
+    mixed = column(np.r_[0, rng.integers(4, 256, A - 1)])
+    too_long = column(np.r_[0, rng.integers(4, 50, A - 2), 256])
+    encs = [_dict_str(rng, c, n) for c in (full, mixed, too_long)]
+    labels = ["entries of 255 bytes", "entries of 0 .. 255 bytes", "one entry of 256 bytes"]
+    assert "k_dict_str<8>" in _names(encs[0]) and "k_dict_str<8>" in _names(encs[1])
+    assert "k_dict_str<8>" not in _names(encs[2])
+    mask = rng.random(n) < 0.6
+    encs.append(E.nullable_wrap(_dict_str(rng, full, int(mask.sum())), mask, E.Trivial(), W.STRING))
+    labels.append("nullable, entries of 255 bytes")
+    check_parity(oracle, encs, labels=labels)
+
+
+def test_compact_views_gathered_inside_a_rank_scatter(gpu, oracle):
+    rng = np.random.default_rng(77)
+    encs, labels = [], []
+    for A in (4097, 65_536):
+        alpha = _alphabet(rng, A)
+        for n in (5, 65_536, 65_537, 140_000):
+            for frac, nulls in ((0.0, E.Trivial()), (0.05, E.SparseBool()), (0.5, E.Trivial()), (0.95, E.SparseBool()), (1.0, E.Trivial())):
+                mask = rng.random(n) < frac
+                encs.append(E.nullable_wrap(_dict_str(rng, alpha, int(mask.sum())), mask, nulls, W.STRING))
+                labels.append(f"nullable strings alphabet {A} rows {n} non-null {frac}")
+    names = _names(encs[labels.index("nullable strings alphabet 65536 rows 140000 non-null 0.5")])
+    assert "k_dict_str<8>" in names and not any(k.startswith("k_select_scatter") for k in names)
+    check_parity(oracle, encs, labels=labels)
+
+
+def test_index_out_of_range_is_reported_by_the_compact_views_kernel(gpu):
+    rng = np.random.default_rng(78)
+    A, n = 6000, 80_000
+    alpha = _alphabet(rng, A)
+    idx = rng.integers(0, A, n).astype(np.uint32)
+    idx[[3, 40_000, n - 1]] = (A, 65_535, A + 9)  # the kernel takes bit-packed indices of up to 16 bits
+    alpha_enc = E.encode(E.Trivial(lengths=E.FixedBitWidth()), alpha, W.STRING)
+    enc = E.prefix(W.DICTIONARY, W.STRING, n) + struct.pack("<I", len(alpha_enc)) + alpha_enc + E.encode(E.FixedBitWidth(), idx, W.UINT32)
+    assert "k_dict_str<8>" in _names(enc)
+    plan = Plan.from_encodings([enc], lds_dictionary_min_tiles=1)
+    dec = BatchDecoder(plan)
+    dec.stage()
+    dec.decode()
+    with pytest.raises(capi.NimbleError, match="dictionary index") as ei:
+        dec.status()
+    assert ei.value.status == capi.NBL_ERR_DEVICE_DATA
+    dec.fetch()
+    plan.close()
