@@ -2620,6 +2620,19 @@ __device__ __forceinline__ void body_dict_str(const KArgs& a, const NodeDesc& nd
   const uint32_t lane = lane_id(), wv = wave_id();
   uint32_t* s_parts = reinterpret_cast<uint32_t*>(smem + kDictStrTableBytes);
   if (scatter && group == 0 && threadIdx.x == 0 && sload32(a.totals + nd.total_idx) != nvals) atomicOr(a.status, ST_SELECT_COUNT);
+  // The bitmap words of the wave's two tiles (lanes 0 .. 31: tile wv, 32 .. 63:
+  // tile wv + 16) are requested before the table, so they arrive under its copy.
+  const uint32_t half = lane >> 5, tl = wv + kDictStrWaves * half;
+  const uint32_t my_t = t_begin + tl;
+  const uint64_t my_w = (uint64_t)my_t * W + (lane & 31u);
+  uint64_t word = 0;
+  if (tl < n_t && my_w * 64 < rows) {
+    if (scatter) word = BitsReader(nd.sel, a, invert).word(my_w);
+    else word = my_w * 64 + 64 > rows ? wmask((uint32_t)(rows - my_w * 64)) : ~0ull;  // every row takes the index of its own number
+  }
+  // so are the group's rank partials, one per tile (the node's total sits behind its last one)
+  uint32_t part = 0;
+  if (scatter && threadIdx.x < n_t) part = a.parts[pslot0 + threadIdx.x];
   {  // the table: a straight copy, eight loads of a thread in flight together
     const u32x4* src = reinterpret_cast<const u32x4*>(a.work + nd.aux3);
     u32x4* dst = reinterpret_cast<u32x4*>(smem);
@@ -2638,8 +2651,7 @@ __device__ __forceinline__ void body_dict_str(const KArgs& a, const NodeDesc& nd
         if (i < nvec) dst[i] = q[u];
       }
     }
-    // the group's rank partials, one per tile (the node's total sits behind its last one)
-    if (scatter && threadIdx.x < n_t) s_parts[threadIdx.x] = a.parts[pslot0 + threadIdx.x];
+    if (scatter && threadIdx.x < n_t) s_parts[threadIdx.x] = part;
   }
   __syncthreads();  // the only one
   const uint32_t* s_coarse = reinterpret_cast<const uint32_t*>(smem);
@@ -2656,22 +2668,14 @@ __device__ __forceinline__ void body_dict_str(const KArgs& a, const NodeDesc& nd
   uint64_t* s_words = reinterpret_cast<uint64_t*>(mine + kDictStrWaveStage);  // words of tile wv (0 .. 31) and of tile wv + 16 (32 .. 63)
   uint32_t* s_pref = reinterpret_cast<uint32_t*>(mine + kDictStrWaveStage + 64 * 8);  // rank of each word's first row; [64], [65]: ranks behind the tiles
   {
-    const uint32_t half = lane >> 5, tl = wv + kDictStrWaves * half;
-    const uint32_t t = t_begin + tl;
-    const uint64_t w = (uint64_t)t * W + (lane & 31u);
-    const bool live = tl < n_t && w * 64 < rows;
-    uint64_t word = 0;
-    if (live) {
-      if (scatter) word = BitsReader(nd.sel, a, invert).word(w);
-      else word = w * 64 + 64 > rows ? wmask((uint32_t)(rows - w * 64)) : ~0ull;  // every row takes the index of its own number
-      if (scatter && (nd.flags & NF_WRITE_NULLS))
-        reinterpret_cast<uint64_t*>(a.out + nd.aux_off)[w] = invert ? ~word & (w * 64 + 64 > rows ? wmask((uint32_t)(rows - w * 64)) : ~0ull) : word;
-    }
+    if (scatter && (nd.flags & NF_WRITE_NULLS) && tl < n_t && my_w * 64 < rows)
+      reinterpret_cast<uint64_t*>(a.out + nd.aux_off)[my_w] =
+          invert ? ~word & (my_w * 64 + 64 > rows ? wmask((uint32_t)(rows - my_w * 64)) : ~0ull) : word;
     const uint32_t pc = (uint32_t)__popcll(word);
     const uint32_t incl = wave_incl_scan(pc);
     const uint32_t low = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);  // rows selected in the first of the two tiles
     uint32_t first = 0;  // rank of the tile's first row
-    if (tl < n_t) first = scatter ? s_parts[tl] : t * TE;
+    if (tl < n_t) first = scatter ? s_parts[tl] : my_t * TE;
     const uint32_t excl = first + incl - pc - (half ? low : 0u);
     s_words[lane] = word;
     s_pref[lane] = excl;

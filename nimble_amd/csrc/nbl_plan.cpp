@@ -1331,6 +1331,14 @@ void nbl_plan::finish() {
         // short tiles filling the gaps instead of a few long ones running alone.
         if (steps[i].kernel == K_SPARSE_BITS && j - i >= kGroupVariantsFrom)
           reorder(i, j, [&](const Step& x) { return ~(dnodes[x.dnode].c0.rows / x.n_tiles); });
+        // A compact-views workgroup has its CU to itself and first copies its
+        // alphabet's table: the ones with the largest tables go first, so the
+        // launch ends on the short ones.
+        if (steps[i].kernel == K_DICT_STR && j - i > 1)
+          reorder(i, j, [&](const Step& x) {
+            const NodeDesc& d = dnodes[x.dnode];
+            return ~((d.flags & NF_DICT_VALUES) ? d.c0.rows : d.c1.rows);
+          });
         i = j;
       }
     }

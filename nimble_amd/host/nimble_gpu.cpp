@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cstring>
 #include <atomic>
+#include <chrono>
 #include <exception>
 #include <mutex>
 #include <thread>
@@ -188,12 +189,15 @@ class GpuContext {
     std::mutex mu;
     hipStream_t stream = nullptr;
     DeviceBuffer arena, out, work;
+    hipEvent_t decodeBegin = nullptr, decodeEnd = nullptr;  // created on the first batch that asks for statistics
   };
   explicit GpuContext(int device) : device_(device) {}
   ~GpuContext() {
     for (Slot& s : slots_)
       if (s.stream) {
         (void)hipStreamSynchronize(s.stream);
+        if (s.decodeBegin) (void)hipEventDestroy(s.decodeBegin);
+        if (s.decodeEnd) (void)hipEventDestroy(s.decodeEnd);
         (void)hipStreamDestroy(s.stream);
       }
   }
@@ -537,6 +541,43 @@ struct StagedBatch {
   std::shared_ptr<uint8_t> staging;  // pinned image of the arena; alive until the copy has been waited for
 };
 
+// Host and device time of one batch for Options::decodingStats.  Host time is
+// the caller's wall time with the parallel copy / inflate phases counted by
+// what their tasks took on every thread, so the inflating time reported
+// beside it is a part of it whatever the thread count.
+using StatClock = std::chrono::steady_clock;
+inline uint64_t nanosSince(StatClock::time_point t) {
+  return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(StatClock::now() - t).count();
+}
+struct BatchTimer {
+  DecodingStats* stats;
+  StatClock::time_point begin = StatClock::now();
+  uint64_t phaseNanos = 0;                // wall time of the parallel phases
+  std::atomic<uint64_t> taskNanos{0};     // time of their tasks, all threads
+  explicit BatchTimer(DecodingStats* s) : stats(s) {}
+  void deviceBegin(GpuContext::Slot& slot) {
+    if (!stats) return;
+    if (!slot.decodeBegin) {
+      hipCheck(hipEventCreate(&slot.decodeBegin), "hipEventCreate");
+      hipCheck(hipEventCreate(&slot.decodeEnd), "hipEventCreate");
+    }
+    hipCheck(hipEventRecord(slot.decodeBegin, slot.stream), "hipEventRecord");
+  }
+  void deviceEnd(GpuContext::Slot& slot) {
+    if (stats) hipCheck(hipEventRecord(slot.decodeEnd, slot.stream), "hipEventRecord");
+  }
+  // after the slot's stream has been synchronised
+  void finish(GpuContext::Slot& slot, const nbl_plan_info& info, uint64_t stagedBytes) {
+    if (!stats) return;
+    float ms = 0;
+    hipCheck(hipEventElapsedTime(&ms, slot.decodeBegin, slot.decodeEnd), "hipEventElapsedTime");
+    stats->deviceNanos.increment((uint64_t)((double)ms * 1e6));
+    stats->encodedBytes.increment(stagedBytes);
+    stats->decodedBytes.increment(info.out_bytes);
+    stats->decodeCPUTimeNanos.increment(nanosSince(begin) - phaseNanos + taskNanos.load());
+  }
+};
+
 // Packs the chunks (16-byte aligned starts) into one pinned staging block -- the
 // image the device arena receives; chunks with Zstd / LZ4 leaf payloads, the
 // reference writer's default, are inflated straight into it -- and copies it to
@@ -545,7 +586,8 @@ struct StagedBatch {
 // next, so a stripe pays the longer of the two instead of their sum.  The plan
 // is made once the last slice is on its way (the header walk reads the staged
 // bytes), i.e. under the tail of the transfer.  The slot is locked by the caller.
-StagedBatch stageBatch(GpuContext& ctx, GpuContext::Slot& slot, const std::vector<std::string_view>& chunks, const Options& opts) {
+StagedBatch stageBatch(GpuContext& ctx, GpuContext::Slot& slot, const std::vector<std::string_view>& chunks, const Options& opts,
+                       BatchTimer& timer, uint64_t& stagedBytes) {
   StagedBatch b;
   const nbl_options o = planOptions(opts);
   std::vector<uint64_t> offs(chunks.size()), sizes(chunks.size());
@@ -566,8 +608,10 @@ StagedBatch stageBatch(GpuContext& ctx, GpuContext::Slot& slot, const std::vecto
     size_t last = first;
     uint64_t bytes = 0;
     while (last < chunks.size() && (bytes == 0 || bytes + sizes[last] <= kSlice)) bytes += (sizes[last++] + 15) & ~uint64_t(15);
+    const auto phase = StatClock::now();
     parallelFor(last - first, bytes, [&](size_t k) {
       const size_t i = first + k;
+      const auto t = StatClock::now();
       if (inflate[i]) {
         uint64_t written = 0;
         check(nbl_chunk_inflate(reinterpret_cast<const uint8_t*>(chunks[i].data()), chunks[i].size(), &o, b.staging.get() + offs[i],
@@ -575,12 +619,21 @@ StagedBatch stageBatch(GpuContext& ctx, GpuContext::Slot& slot, const std::vecto
       } else {
         memcpy(b.staging.get() + offs[i], chunks[i].data(), chunks[i].size());
       }
+      if (timer.stats) {
+        const uint64_t ns = nanosSince(t);
+        timer.taskNanos.fetch_add(ns, std::memory_order_relaxed);
+        if (inflate[i]) timer.stats->decompressCPUTimeNanos.increment(ns);
+      }
     });
+    timer.phaseNanos += nanosSince(phase);
     hipCheck(hipMemcpyAsync(static_cast<uint8_t*>(slot.arena.ptr) + offs[first], b.staging.get() + offs[first], bytes,
                             hipMemcpyHostToDevice, slot.stream), "H2D");
     first = last;
   }
+  const auto planBegin = StatClock::now();
   check(nbl_plan_batch(b.staging.get(), offs.data(), sizes.data(), (uint32_t)chunks.size(), &o, &b.plan.p));
+  if (timer.stats) timer.stats->planNanos.increment(nanosSince(planBegin));
+  stagedBytes = total;
   check(nbl_plan_get_info(b.plan.p, &b.info));
   if (b.info.arena_bytes > slot.arena.cap) throw NimbleError(NBL_ERR_ARGUMENT, "arena smaller than the plan asks for");
   return b;
@@ -597,14 +650,19 @@ std::vector<std::unique_ptr<Encoding>> decodeChunks(GpuContext& ctx, const std::
     GpuContext::Slot* slotp = nullptr;
     std::unique_lock<std::mutex> lock = ctx.acquire(slotp);
     GpuContext::Slot& slot = *slotp;
-    b = stageBatch(ctx, slot, chunks, opts);
+    BatchTimer timer(opts.decodingStats);
+    uint64_t stagedBytes = 0;
+    b = stageBatch(ctx, slot, chunks, opts, timer, stagedBytes);
     hostOut = std::make_shared<OutputCopy>(ctx.pinned->acquire(b.info.out_bytes));
     slot.out.reserve(b.info.out_bytes, slot.stream);
     slot.work.reserve(b.info.work_bytes, slot.stream);
     check(nbl_plan_upload(b.plan.p, slot.work.ptr, slot.stream));
+    timer.deviceBegin(slot);
     check(nbl_decode_batch_device(b.plan.p, slot.arena.ptr, slot.out.ptr, slot.work.ptr, slot.stream));
+    timer.deviceEnd(slot);
     // synchronises the slot's stream: inconsistent payloads are reported before anything is handed out
     check(nbl_decode_status(b.plan.p, slot.work.ptr, slot.stream));
+    timer.finish(slot, b.info, stagedBytes);
     // the copy back runs on while the caller already reads the first chunks and
     // while the next batch is copied in and decoded on the other slot; the batch
     // after that queues behind this copy on this slot's stream
@@ -645,14 +703,19 @@ std::unique_ptr<DeviceBatch> decodeChunksToDevice(const std::shared_ptr<GpuConte
     GpuContext::Slot* slotp = nullptr;
     std::unique_lock<std::mutex> lock = ctx.acquire(slotp);
     GpuContext::Slot& slot = *slotp;
-    b = stageBatch(ctx, slot, chunks, opts);
+    BatchTimer timer(opts.decodingStats);
+    uint64_t stagedBytes = 0;
+    b = stageBatch(ctx, slot, chunks, opts, timer, stagedBytes);
     slot.work.reserve(b.info.work_bytes, slot.stream);
     batch->out.reserve(b.info.out_bytes);   // owned by the batch: it outlives this call
     batch->outBytes = b.info.out_bytes;
     batch->stream_ = slot.stream;
     check(nbl_plan_upload(b.plan.p, slot.work.ptr, slot.stream));
+    timer.deviceBegin(slot);
     check(nbl_decode_batch_device(b.plan.p, slot.arena.ptr, batch->out.ptr, slot.work.ptr, slot.stream));
+    timer.deviceEnd(slot);
     check(nbl_decode_status(b.plan.p, slot.work.ptr, slot.stream));  // synchronises the slot's stream
+    timer.finish(slot, b.info, stagedBytes);
   }
   batch->layouts.resize(chunks.size());
   for (uint32_t c = 0; c < chunks.size(); ++c) check(nbl_plan_get_chunk_layout(b.plan.p, c, &batch->layouts[c]));

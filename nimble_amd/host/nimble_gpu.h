@@ -17,6 +17,7 @@
 // interfaces with a thin adapter that forwards each virtual one-to-one.
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 #include <functional>
 #include <memory>
@@ -66,6 +67,42 @@ enum class DataType : uint8_t {
 std::string toString(EncodingType encodingType);
 std::string toString(DataType dataType);
 
+// velox::io::IoCounter as DecodingStats uses it: count, sum, minimum and maximum
+// of the samples it was given; safe to increment from several threads.
+class IoCounter {
+ public:
+  void increment(uint64_t value) {
+    count_.fetch_add(1, std::memory_order_relaxed);
+    sum_.fetch_add(value, std::memory_order_relaxed);
+    for (uint64_t m = min_.load(std::memory_order_relaxed); value < m && !min_.compare_exchange_weak(m, value, std::memory_order_relaxed);) {}
+    for (uint64_t m = max_.load(std::memory_order_relaxed); value > m && !max_.compare_exchange_weak(m, value, std::memory_order_relaxed);) {}
+  }
+  uint64_t count() const { return count_.load(std::memory_order_relaxed); }
+  uint64_t sum() const { return sum_.load(std::memory_order_relaxed); }
+  uint64_t min() const { return count() ? min_.load(std::memory_order_relaxed) : 0; }
+  uint64_t max() const { return max_.load(std::memory_order_relaxed); }
+
+ private:
+  std::atomic<uint64_t> count_{0}, sum_{0}, min_{~0ull}, max_{0};
+};
+
+// velox::dwio::common::DecodingStats as Encoding::Options::decodingStats hands it
+// to the encodings (dwio/nimble/encodings/common/Encoding.h:160-170): the
+// reference times decompression into it per column, and its readers expect
+// decompression to be a part of the decode time
+// (velox/selective/tests/SelectiveNimbleReaderTest.cpp:2805-2822).  Here a
+// sample is a batch -- a chunk handed to create(), or all chunks of a stripe --
+// since that is what the device decodes at once.
+struct DecodingStats {
+  IoCounter decodeCPUTimeNanos;      // host time of a batch: staging, inflating (all threads), planning, launching, the wait for the status
+  IoCounter decompressCPUTimeNanos;  // of that, inflating Zstd / LZ4 payloads: one sample per inflated chunk
+  // Not in the reference: what a batch moved and what it cost beside the host's time.
+  IoCounter encodedBytes;            // bytes staged for the device (after inflating)
+  IoCounter decodedBytes;            // bytes of decoded output
+  IoCounter planNanos;               // the header walk (nbl_plan_batch), part of decodeCPUTimeNanos
+  IoCounter deviceNanos;             // device time from the first to the last kernel of the decode
+};
+
 // Encoding::Options fields that matter on the decode side (Encoding.h:115-175).
 struct Options {
   bool useVarintRowCount = false;
@@ -73,6 +110,8 @@ struct Options {
   // dictionary-encoded chunks, which turns on the dictionary API below
   // (costs 4 more bytes per row over the link).
   bool keepDictionary = false;
+  // Encoding.h:160-161; may be shared by factories and threads, must outlive the decodes.
+  DecodingStats* decodingStats = nullptr;
 };
 
 // Same contract as nimble::Encoding: a row cursor over one decoded chunk.

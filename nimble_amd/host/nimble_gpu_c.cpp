@@ -22,6 +22,7 @@ struct EncHandle {
   std::vector<std::unique_ptr<char[]>> strings;  // stringBufferFactory memory
 };
 struct FactoryHandle {
+  DecodingStats stats;  // named by the factory's options when the flags word asks for statistics
   std::unique_ptr<GpuEncodingFactory> f;
 };
 struct StripeHandle {
@@ -58,11 +59,24 @@ void* nblh_factory_create(int use_varint_row_count, int device) {
     Options o;
     o.useVarintRowCount = (use_varint_row_count & 1) != 0;
     o.keepDictionary = (use_varint_row_count & 2) != 0;  // bit 1 of the flags word
+    if (use_varint_row_count & 4) o.decodingStats = &h->stats;  // bit 2
     h->f = std::make_unique<GpuEncodingFactory>(o, device);
   });
   return h;
 }
 void nblh_factory_free(void* f) { delete static_cast<FactoryHandle*>(f); }
+
+// {count, sum, min, max} of decodeCPUTimeNanos, decompressCPUTimeNanos, encodedBytes, decodedBytes, planNanos, deviceNanos: 24 values
+void nblh_factory_stats(void* f, uint64_t* out) {
+  const DecodingStats& s = static_cast<FactoryHandle*>(f)->stats;
+  const IoCounter* all[6] = {&s.decodeCPUTimeNanos, &s.decompressCPUTimeNanos, &s.encodedBytes, &s.decodedBytes, &s.planNanos, &s.deviceNanos};
+  for (int i = 0; i < 6; ++i) {
+    out[4 * i] = all[i]->count();
+    out[4 * i + 1] = all[i]->sum();
+    out[4 * i + 2] = all[i]->min();
+    out[4 * i + 3] = all[i]->max();
+  }
+}
 
 void* nblh_encoding_create(void* factory, const char* data, uint64_t size) {
   EncHandle* h = new EncHandle();

@@ -33,6 +33,7 @@ def lib():
         L.nblh_factory_create.restype = vp
         L.nblh_factory_create.argtypes = [i32, i32]
         L.nblh_factory_free.argtypes = [vp]
+        L.nblh_factory_stats.argtypes = [vp, vp]
         L.nblh_encoding_create.restype = vp
         L.nblh_encoding_create.argtypes = [vp, vp, u64]
         L.nblh_encoding_free.argtypes = [vp]
@@ -124,10 +125,17 @@ def _p(a):
 
 
 class Factory:
-    def __init__(self, varint_rows: bool = False, device: int = 0, keep_dictionary: bool = False):
-        self._h = lib().nblh_factory_create(int(varint_rows) | (2 if keep_dictionary else 0), device)
+    def __init__(self, varint_rows: bool = False, device: int = 0, keep_dictionary: bool = False, collect_stats: bool = False):
+        self._h = lib().nblh_factory_create(int(varint_rows) | (2 if keep_dictionary else 0) | (4 if collect_stats else 0), device)
         if not self._h:
             _chk(-1)
+
+    def stats(self) -> dict:
+        """Options::decodingStats of a factory made with collect_stats: per counter {count, sum, min, max}."""
+        raw = np.zeros(24, dtype=np.uint64)
+        lib().nblh_factory_stats(self._h, _p(raw))
+        names = ("decodeCPUTimeNanos", "decompressCPUTimeNanos", "encodedBytes", "decodedBytes", "planNanos", "deviceNanos")
+        return {n: dict(count=int(raw[4 * i]), sum=int(raw[4 * i + 1]), min=int(raw[4 * i + 2]), max=int(raw[4 * i + 3])) for i, n in enumerate(names)}
 
     def create(self, data) -> "HostEncoding":
         return HostEncoding(self, data)

@@ -228,6 +228,40 @@ def test_compressed_leaves_and_chunks_decode_like_their_uncompressed_twins(facto
         assert nn == n and np.array_equal(out, ints.view(np.uint64))
 
 
+def test_decoding_statistics(gpu):
+    """Options::decodingStats (encodings/common/Encoding.h:160-170): decompression is timed per inflated chunk and is
+    a part of the decode time, as velox/selective/tests/SelectiveNimbleReaderTest.cpp:2805-2822 expects; a sample of
+    the decode time is a batch.  Bytes moved, planning and device time are this build's additions."""
+    pytest.importorskip("pyarrow")
+    import host_shim
+
+    f = host_shim.Factory(collect_stats=True)
+    rng = np.random.default_rng(22)
+    n = 200_000
+    ints = np.repeat(rng.integers(0, 500, n // 8 + 1), 8)[:n].astype(np.int64)
+    plain = E.encode(E.FixedBitWidth(), ints, W.INT64)
+    e = f.create(plain)
+    assert np.array_equal(e.materialize(n), ints.view(np.uint64))
+    s = f.stats()
+    assert s["decodeCPUTimeNanos"]["count"] == 1 and s["decompressCPUTimeNanos"]["count"] == 0
+    assert s["encodedBytes"]["sum"] >= len(plain) and s["decodedBytes"]["sum"] >= 8 * n
+    assert 0 < s["planNanos"]["sum"] <= s["decodeCPUTimeNanos"]["sum"] and s["deviceNanos"]["sum"] > 0
+    # a stripe: one stream whose chunk is compressed as a whole, one whose leaves are, one plain
+    zstd_leaves = E.encode(E.RLE(lengths=E.FixedBitWidth(compression="zstd"), values=E.Trivial(compression="zstd")), ints, W.INT64)
+    streams = [E.chunk(plain, "zstd"), E.chunk(zstd_leaves), E.chunk(plain)]
+    dec = host_shim.StripeDecoder(f, streams)
+    for i in range(3):
+        out = np.zeros(n, dtype=np.uint64)
+        nn, _ = dec.stream(i).next(n, out)
+        assert nn == n and np.array_equal(out, ints.view(np.uint64))
+    s2 = f.stats()
+    assert s2["decodeCPUTimeNanos"]["count"] == 2  # the stripe was one batch
+    assert s2["decompressCPUTimeNanos"]["count"] >= 1  # the chunk with compressed leaves (whole-chunk compression is undone before the batch)
+    assert 0 < s2["decompressCPUTimeNanos"]["sum"] <= s2["decodeCPUTimeNanos"]["sum"]
+    assert s2["decodedBytes"]["sum"] - s["decodedBytes"]["sum"] >= 3 * 8 * n
+    assert s2["decodeCPUTimeNanos"]["min"] <= s2["decodeCPUTimeNanos"]["max"]
+
+
 def test_device_resident_batch(factory, oracle):
     """decodeToDevice leaves the decoded chunks in device memory; copied back,
     they are what the oracle decodes."""
