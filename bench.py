@@ -394,12 +394,21 @@ def roofline_of(by, workload, rows, launches_per_step_of=1):
     }
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         pmc = json.load(open(path))
-        k = pmc.get("kernels", {}).get(dom_key)
+        kernels = pmc.get("kernels", {})
+        k = kernels.get(dom_key) or kernels.get(dom_key.split("<")[0])  # the profiler prints non-template kernels without "<es>"
         if pmc.get("rows") == rows and pmc.get("workload", "fbw_rle") == workload and k:
             roofline["traffic"] = k["traffic_bytes"]
             roofline["traffic_over_algorithmic"] = round(k["traffic_bytes"] / max(roofline["algorithmic_bytes_per_launch"], 1), 4)
             roofline["traffic_source"] = os.path.relpath(path, ROOT)
             break
+    # A launch is credited with B_enc + B_out of the chunks it finishes.  For string chunks that includes the string
+    # bytes, which the level before copied: where the measured traffic is smaller than the credit, the launch cannot
+    # have moved the credited bytes, and its rate is taken from the traffic instead.
+    if roofline["traffic"] and roofline["traffic"] < roofline["algorithmic_bytes_per_launch"] and dom["ms"] > 0:
+        moved = roofline["traffic"] * max(dom["launches"], 1) / (dom["ms"] * 1e-3) / 1e9
+        roofline["achieved"] = round(moved, 1)
+        roofline["frac"] = round(moved / HBM_PEAK_GBS, 4)
+        roofline["achieved_from"] = "traffic (smaller than the bytes credited to the launch, which include string bytes the level before moved)"
     return roofline
 
 
