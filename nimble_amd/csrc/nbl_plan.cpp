@@ -184,6 +184,12 @@ struct Launch {
   std::string name;     // as a profiler shows it, e.g. "k_materialize_fbw<8>", "k_level<true>"
 };
 
+// toString(DataType), dwio/nimble/common/Types.cpp
+const char* data_type_name(uint32_t dt) {
+  static const char* const names[] = {"Undefined", "Int8", "Uint8", "Int16", "Uint16", "Int32", "Uint32", "Int64", "Uint64", "Float", "Double", "Bool", "String"};
+  return dt < sizeof names / sizeof names[0] ? names[dt] : "Unknown";
+}
+
 const char* kKernelNames[K_COUNT] = {
     "k_materialize", "k_bits_to_bytes", "k_reduce_popc", "k_rle_ends", "k_rle_expand", "k_rle_expand_bool", "k_sparse_bits",
     "k_select_scatter", "k_dict_gather", "k_varint_decode", "k_string_views", "k_copy_bytes",
@@ -391,7 +397,7 @@ int nbl_plan::parse(uint64_t off, uint64_t size, int chunk, int depth) {
       break;
     }
     case ET_FIXEDBITWIDTH: {  // FixedBitWidthEncoding.h:149-175
-      NBL_CHECK(!n.is_bool && !n.is_string, "FixedBitWidth needs a numeric data type");
+      NBL_CHECK(!n.is_bool && !n.is_string, "Trying to deserialize a non-numeric stream for a numeric data type %s.", data_type_name(n.dtype));
       NBL_CHECK(pos + 2 + n.es <= end, "FixedBitWidth header beyond end");
       if (u8(pos) != 0) fail(NBL_ERR_UNSUPPORTED, "compressed FixedBitWidth payload (CompressionType %d)", (int)u8(pos));
       N().value = le(pos + 1, n.es);
@@ -406,7 +412,7 @@ int nbl_plan::parse(uint64_t off, uint64_t size, int chunk, int depth) {
       break;
     }
     case ET_VARINT: {  // VarintEncoding.h:94-111
-      NBL_CHECK(!n.is_bool && !n.is_string && (n.es == 4 || n.es == 8), "Varint needs a 4- or 8-byte numeric type");
+      NBL_CHECK(!n.is_bool && !n.is_string && (n.es == 4 || n.es == 8), "Trying to deserialize a varint stream for an incompatible data type %s.", data_type_name(n.dtype));
       NBL_CHECK(pos + n.es <= end, "Varint header beyond end");
       N().value = le(pos, n.es);
       pos += n.es;
@@ -440,7 +446,7 @@ int nbl_plan::parse(uint64_t off, uint64_t size, int chunk, int depth) {
       break;
     }
     case ET_DICTIONARY: {  // DictionaryEncoding.h:193-214
-      NBL_CHECK(!n.is_bool, "Dictionary does not support bool");
+      NBL_CHECK(!n.is_bool, "Trying to deserialize a non-bool stream for the bool data type %s.", data_type_name(n.dtype));
       NBL_CHECK(pos + 4 <= end, "Dictionary header beyond end");
       const uint32_t asize = u32(pos);
       pos += 4;
@@ -480,7 +486,7 @@ int nbl_plan::parse(uint64_t off, uint64_t size, int chunk, int depth) {
       break;
     }
     case ET_MAINLYCONSTANT: {  // MainlyConstantEncoding.h:842-860, MainlyConstantEncoding.cpp:21-43
-      NBL_CHECK(!n.is_bool, "MainlyConstant does not support bool");
+      NBL_CHECK(!n.is_bool, "Trying to deserialize a non-bool stream for the bool data type %s.", data_type_name(n.dtype));
       NBL_CHECK(pos + 4 <= end, "MainlyConstant header beyond end");
       const uint32_t isize = u32(pos);
       pos += 4;
@@ -503,8 +509,8 @@ int nbl_plan::parse(uint64_t off, uint64_t size, int chunk, int depth) {
     case ET_FOR: {            // ForEncoding.h:174-196,316-383
       const bool frames = n.enc == ET_FOR;
       const char* name = frames ? "FOR" : "BlockBitPacking";
-      if (frames) NBL_CHECK(n.dtype >= DT_INT8 && n.dtype <= DT_UINT64, "FOR needs an integer data type");
-      else NBL_CHECK(!n.is_bool && !n.is_string, "BlockBitPacking needs a numeric data type");
+      if (frames) NBL_CHECK(n.dtype >= DT_INT8 && n.dtype <= DT_UINT64, "Trying to deserialize an integer stream for an incompatible data type %s.", data_type_name(n.dtype));
+      else NBL_CHECK(!n.is_bool && !n.is_string, "Trying to deserialize a non-numeric stream for a numeric data type %s.", data_type_name(n.dtype));
       auto varint = [&]() {  // varint::readVarint32, common/Varint.h:104-125
         uint32_t v = 0;
         for (int k = 0; k < 5; ++k) {

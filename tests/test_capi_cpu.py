@@ -130,6 +130,28 @@ def test_malformed_and_unsupported_inputs():
     _expect(capi.NimbleCorruptError, bytes(r), "beyond end")
 
 
+def test_data_types_an_encoding_cannot_carry_are_refused_in_the_reference_words():
+    """The factory's dispatch by data type (encodings/common/EncodingFactory.cpp:71-160 with the macros of
+    EncodingTypeDispatch.h:24-68): which encodings take which data types, and what the refusal says."""
+    def bare(encoding_type, data_type):  # a prefix alone: the data type is looked at before anything behind it
+        return bytes([encoding_type, data_type]) + struct.pack("<I", 1) + bytes(40)
+    cases = [
+        (W.FIXED_BIT_WIDTH, W.STRING, "Trying to deserialize a non-numeric stream for a numeric data type String."),
+        (W.FIXED_BIT_WIDTH, W.BOOL, "Trying to deserialize a non-numeric stream for a numeric data type Bool."),
+        (W.BLOCK_BIT_PACKING, W.STRING, "Trying to deserialize a non-numeric stream for a numeric data type String."),
+        (W.VARINT, W.INT16, "Trying to deserialize a varint stream for an incompatible data type Int16."),
+        (W.VARINT, W.STRING, "Trying to deserialize a varint stream for an incompatible data type String."),
+        (W.DICTIONARY, W.BOOL, "Trying to deserialize a non-bool stream for the bool data type Bool."),
+        (W.MAINLY_CONSTANT, W.BOOL, "Trying to deserialize a non-bool stream for the bool data type Bool."),
+        (W.FOR, W.FLOAT, "Trying to deserialize an integer stream for an incompatible data type Float."),
+        (W.SPARSE_BOOL, W.INT32, "Trying to deserialize a SparseBoolEncoding with a non-bool data type."),
+    ]
+    for et, dt, message in cases:
+        with pytest.raises(capi.NimbleCorruptError) as ei:
+            Plan.from_encodings([bare(et, dt)])
+        assert message in ei.value.message, (et, dt, ei.value.message)
+
+
 def test_split_stream():
     e1 = E.encode(E.Trivial(), np.arange(5, dtype=np.int32), W.INT32)
     e2 = E.encode(E.FixedBitWidth(), np.arange(9, dtype=np.int64), W.INT64)
