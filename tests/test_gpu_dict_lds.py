@@ -203,6 +203,16 @@ def test_compact_views_gathered_inside_a_rank_scatter(gpu, oracle):
                 labels.append(f"nullable strings alphabet {A} rows {n} non-null {frac}")
     names = _names(encs[labels.index("nullable strings alphabet 65536 rows 140000 non-null 0.5")])
     assert "k_dict_str<8>" in names and not any(k.startswith("k_select_scatter") for k in names)
+    # MainlyConstant<string> whose other values are such a dictionary: the selection is read inverted, the fill is a view
+    n = 90_000
+    alpha = _alphabet(rng, 3000).to_list()
+    common = b"the common one"
+    pick = rng.integers(0, 3000, n)
+    items = [common if c else alpha[i] for c, i in zip(rng.random(n) < 0.7, pick)]
+    spec = E.MainlyConstant(is_common=E.Trivial(), other=E.Dictionary(alphabet=E.Trivial(lengths=E.FixedBitWidth()), indices=E.FixedBitWidth()))
+    encs.append(E.encode(spec, E.StringColumn.from_list(items), W.STRING))
+    labels.append("mainly constant strings over a 3000-entry dictionary")
+    assert "k_dict_str<8>" in _names(encs[-1])
     check_parity(oracle, encs, labels=labels)
 
 
