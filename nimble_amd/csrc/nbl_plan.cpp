@@ -163,6 +163,7 @@ struct NoInit : std::allocator<T> {
 template <class T>
 using RawVec = std::vector<T, NoInit<T>>;
 
+constexpr uint32_t kNoAux = 0xFFFFFFFFu;
 struct Step {
   int level;
   uint32_t kernel;
@@ -174,6 +175,10 @@ struct Step {
   uint32_t tile_begin;  // first tile of the node this step covers (steps can be split)
   uint64_t alg;         // algorithmic bytes credited to this step (set by finish())
   bool filler;          // a free step placed in a level to fill it: its tiles go after the level's own
+  uint32_t aux_base;    // rank scatters (a Dictionary gathered inside one included): first slot of the node's scanned rank
+                        // partials, from which the tile table's tile_aux entries count; kNoAux otherwise
+  uint32_t order_key;   // place among the steps of its (level, kernel, element size) where finish() orders those: taken
+                        // from the descriptor while that is in the cache (the descriptors of a wide batch are megabytes)
 };
 
 struct Launch {
@@ -252,7 +257,23 @@ struct nbl_plan {
   void add_step(int level, uint32_t kernel, uint32_t es, uint32_t dnode, uint32_t n_tiles) {
     if (n_tiles == 0) return;
     if (n_tiles > kTileMask) fail(NBL_ERR_UNSUPPORTED, "a node of %u tiles exceeds the tile table's range", n_tiles);
-    steps.push_back(Step{level, kernel, es, dnode, n_tiles, -1, cur_chunk, 0, 0});
+    const NodeDesc& d = dnodes[dnode];
+    const bool ranked = kernel == K_SELECT_SCATTER || kernel == K_SELECT_SCATTER_WAVE ||
+                        ((kernel == K_DICT_LDS || kernel == K_DICT_STR) && (d.flags & NF_DICT_VALUES));
+    steps.push_back(Step{level, kernel, es, dnode, n_tiles, -1, cur_chunk, 0, 0, false, ranked ? d.part_base : kNoAux,
+                         order_key_of(kernel, d, n_tiles)});
+  }
+  // Rank scatters are grouped by what their tiles execute (which values child is
+  // resolved inside, how values and bitmap are read, how dense the selection
+  // is); SparseBool bitmap steps by the positions a tile reads, longest first.
+  static uint32_t order_key_of(uint32_t kernel, const NodeDesc& d, uint32_t n_tiles) {
+    if (kernel == K_SPARSE_BITS) return ~(d.c0.rows / n_tiles);
+    if (kernel == K_SELECT_SCATTER || kernel == K_SELECT_SCATTER_WAVE || kernel == K_DICT_LDS || kernel == K_DICT_STR) {
+      const uint32_t density = d.rows ? (uint32_t)std::min<uint64_t>(7, (uint64_t)d.c1.rows * 8 / d.rows) : 0u;
+      return (d.flags & (NF_NESTED_SELECT | NF_RLE_VALUES | NF_DICT_VALUES | NF_INVERT_SEL)) << 16 | (uint32_t)d.c1.kind << 12 |
+             (uint32_t)(d.c1.width > 25) << 11 | (uint32_t)d.sel.kind << 4 | density;
+    }
+    return 0;
   }
   // A node whose positions depend on its data: the totals slot (total, flag
   // word, ticket counter, spare), `chain_tiles` look-back words for a chained
@@ -1117,6 +1138,7 @@ void nbl_plan::copy_from(const nbl_plan& sub, const MergeBase& b) {
   for (size_t i = 0; i < sub.steps.size(); ++i) {
     Step st = sub.steps[i];
     st.dnode += (uint32_t)b.dnode;
+    if (st.aux_base != kNoAux) st.aux_base += (uint32_t)b.parts;
     if (st.chunk >= 0) st.chunk += (int)b.chunk;
     if (st.owner >= 0) st.owner += (int)b.chunk;
     steps[b.step + i] = st;
@@ -1293,12 +1315,15 @@ void nbl_plan::finish() {
       const size_t cls = !kernel_is_fusable(st.kernel) ? 2 : st.filler ? 1 : 0;
       return (((size_t)st.level * 3 + cls) * K_COUNT + st.kernel) * 4 + es_slot(st.es);
     };
+    // The order is worked out on step numbers; the steps themselves move once.
     std::vector<uint32_t> first((size_t)(last_level + 1) * 3 * K_COUNT * 4 + 1, 0);
     for (const Step& st : steps) ++first[key(st) + 1];
     for (size_t i = 1; i < first.size(); ++i) first[i] += first[i - 1];
-    RawVec<Step> sorted(steps.size());
-    for (const Step& st : steps) sorted[first[key(st)]++] = st;
-    steps.swap(sorted);
+    RawVec<uint32_t> perm(steps.size());
+    {
+      std::vector<uint32_t> next(first.begin(), first.end() - 1);
+      for (size_t k = 0; k < steps.size(); ++k) perm[next[key(steps[k])]++] = (uint32_t)k;
+    }
     // Rank scatters of one (level, element size) are grouped by what their tiles
     // execute -- which values child is resolved inside, how values and bitmap
     // are read, how dense the selection is -- so that the workgroups resident
@@ -1309,45 +1334,54 @@ void nbl_plan::finish() {
     // is kept inside a group.
     constexpr size_t kGroupVariantsFrom = 256;
     {
-      auto variant = [&](const Step& st) -> uint32_t {
-        const NodeDesc& d = dnodes[st.dnode];
-        const uint32_t density = d.rows ? (uint32_t)std::min<uint64_t>(7, (uint64_t)d.c1.rows * 8 / d.rows) : 0u;
-        return (d.flags & (NF_NESTED_SELECT | NF_RLE_VALUES | NF_DICT_VALUES | NF_INVERT_SEL)) << 16 | (uint32_t)d.c1.kind << 12 |
-               (uint32_t)(d.c1.width > 25) << 11 | (uint32_t)d.sel.kind << 4 | density;
-      };
-      // a group is ordered by a key computed once per step (the descriptors are
-      // megabytes apart: a comparator that reads them misses the cache every time)
-      std::vector<std::pair<uint64_t, uint32_t>> order;
-      std::vector<Step> group;
+      // a group is ordered by a key taken once per step: a stable radix sort of
+      // (key, step number) pairs, three passes of eleven bits
+      RawVec<uint32_t> ka, kb, ia, ib;
       auto reorder = [&](size_t i, size_t j, auto&& key_of) {
-        order.clear();
-        for (size_t k = i; k < j; ++k) order.emplace_back(((uint64_t)key_of(steps[k]) << 32) | (uint32_t)(k - i), (uint32_t)k);
-        std::sort(order.begin(), order.end());  // the position in the low half keeps equal keys in chunk order
-        group.assign(steps.begin() + (ptrdiff_t)i, steps.begin() + (ptrdiff_t)j);
-        for (size_t k = 0; k < order.size(); ++k) steps[i + k] = group[order[k].second - i];
+        const size_t n = j - i;
+        ka.resize(n); kb.resize(n); ia.resize(n); ib.resize(n);
+        for (size_t k = 0; k < n; ++k) {
+          ia[k] = perm[i + k];
+          ka[k] = key_of(steps[ia[k]]);
+        }
+        for (uint32_t shift = 0; shift < 33; shift += 11) {
+          uint32_t count[2049] = {0};
+          for (size_t k = 0; k < n; ++k) ++count[((ka[k] >> shift) & 2047u) + 1];
+          for (uint32_t d = 1; d <= 2048; ++d) count[d] += count[d - 1];
+          for (size_t k = 0; k < n; ++k) {
+            const uint32_t at = count[(ka[k] >> shift) & 2047u]++;
+            kb[at] = ka[k];
+            ib[at] = ia[k];
+          }
+          ka.swap(kb);
+          ia.swap(ib);
+        }
+        for (size_t k = 0; k < n; ++k) perm[i + k] = ia[k];
       };
-      for (size_t i = 0; i < steps.size();) {
-        size_t j = i;
-        while (j < steps.size() && key(steps[j]) == key(steps[i])) ++j;
-        if ((steps[i].kernel == K_SELECT_SCATTER || steps[i].kernel == K_SELECT_SCATTER_WAVE) && j - i >= kGroupVariantsFrom)
-          reorder(i, j, variant);
+      auto cached = [](const Step& st) -> uint32_t { return st.order_key; };
+      for (size_t g = 0; g + 1 < first.size(); ++g) {
+        const size_t i = first[g], j = first[g + 1];
+        if (j - i < 2) continue;
+        const uint32_t kernel = steps[perm[i]].kernel;
         // Bitmap tiles of SparseBool columns cost in proportion to the positions
         // they read (a column of 20,000 takes ten rounds of loads, one of 1,000
         // a single one): the long ones go first, so that the level ends with
         // short tiles filling the gaps instead of a few long ones running alone.
-        if (steps[i].kernel == K_SPARSE_BITS && j - i >= kGroupVariantsFrom)
-          reorder(i, j, [&](const Step& x) { return ~(dnodes[x.dnode].c0.rows / x.n_tiles); });
+        if ((kernel == K_SELECT_SCATTER || kernel == K_SELECT_SCATTER_WAVE || kernel == K_SPARSE_BITS) && j - i >= kGroupVariantsFrom)
+          reorder(i, j, cached);
         // A compact-views workgroup has its CU to itself and first copies its
         // alphabet's table: the ones with the largest tables go first, so the
         // launch ends on the short ones.
-        if (steps[i].kernel == K_DICT_STR && j - i > 1)
+        if (kernel == K_DICT_STR)
           reorder(i, j, [&](const Step& x) {
             const NodeDesc& d = dnodes[x.dnode];
             return ~((d.flags & NF_DICT_VALUES) ? d.c0.rows : d.c1.rows);
           });
-        i = j;
       }
     }
+    RawVec<Step> sorted(steps.size());
+    for (size_t k = 0; k < steps.size(); ++k) sorted[k] = steps[perm[k]];
+    steps.swap(sorted);
   }
   clock.mark("sort");
   {
@@ -1366,10 +1400,8 @@ void nbl_plan::finish() {
     while (j < steps.size() && steps[j].level == steps[i].level &&
            (fuse ? kernel_is_fusable(steps[j].kernel) : (steps[j].kernel == steps[i].kernel && steps[j].es == steps[i].es))) {
       const uint32_t op = op_of(steps[j].kernel, steps[j].es) << kOpShift;
-      const bool lds_dict = steps[j].kernel == K_DICT_LDS || steps[j].kernel == K_DICT_STR;  // an entry is a group of tiles
-      const bool scatter = steps[j].kernel == K_SELECT_SCATTER || steps[j].kernel == K_SELECT_SCATTER_WAVE ||
-                           (lds_dict && (dnodes[steps[j].dnode].flags & NF_DICT_VALUES));
-      const uint32_t aux_base = scatter ? dnodes[steps[j].dnode].part_base : 0u;
+      const bool scatter = steps[j].aux_base != kNoAux;
+      const uint32_t aux_base = scatter ? steps[j].aux_base : 0u;
       if (steps[j].filler && !fillers) { fillers = true; first_filler = n_filled; }
       {
         TileRef* tr = tiles.data() + n_filled;
