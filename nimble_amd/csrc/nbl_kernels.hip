@@ -176,6 +176,16 @@ struct BitsReader {
 
 __device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ uint32_t wave_id() { return threadIdx.x >> 6; }
+// What a workgroup of ONE wave puts where its other bodies have a barrier: the
+// LDS operations of a wave complete in order, so lanes see each other's LDS
+// writes without one; this only keeps the compiler from moving LDS accesses
+// across the point.  (A workgroup barrier would also wait until the wave's
+// global stores have been acknowledged.)
+__device__ __forceinline__ void wave_lds_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
 // Inclusive scan over the 64 lanes of a wave with data-parallel-primitive moves:
 // four shifts inside the 16-lane rows, then the last lane of row 0 / 2 is added
@@ -1929,14 +1939,17 @@ __device__ __forceinline__ void body_select_scatter(const KArgs& a, const NodeDe
     return;
   }
   const uint32_t last = n - 1;
+  // (the copy of the bitmap goes out behind everything the tile loads: a wave's
+  // loads return in order with its stores, so a load issued behind a store
+  // waits for that store to be acknowledged)
   if constexpr (ES >= 4) if (runs) {
-    write_nulls();
     with_reader<ES>(nd.c1, a, [&](auto rd) { select_rle<ES>(a, nd, rd, smem, word, base, n, tile_rows, dst, fill); });
+    write_nulls();
     return;
   }
   if constexpr (ES >= 4) if (nested) {
-    write_nulls();
     with_reader<ES>(nd.c1, a, [&](auto rd) { select_nested<ES>(a, nd, rd, smem, word, base, n, tile_rows, dst, fill); });
+    write_nulls();
     return;
   }
   if constexpr (ES >= 4) if (nd.flags & NF_DICT_VALUES) {  // the planner fuses 4- and 8-byte rows only
@@ -2107,7 +2120,7 @@ __device__ __forceinline__ void wave_select_nested(const KArgs& a, const NodeDes
     s_bits[W + 64 + lane] = iw1; pref2[64 + lane] = e1 | ((e1 + b0) << 16);
   }
   rd.template stage_end<3, kWaveBlock>(regs, bit0, smem);
-  __syncthreads();
+  wave_lds_sync();
   const uint32_t* ob32 = reinterpret_cast<const uint32_t*>(s_bits);
   const uint32_t* ib32 = reinterpret_cast<const uint32_t*>(s_bits + W);
   const uint16_t* ipref = s_pref + 2 * W;
@@ -2132,7 +2145,7 @@ __device__ __forceinline__ void wave_select_nested(const KArgs& a, const NodeDes
       bit0 = 0;
       if (kcount) bit0 = rd.template stage_begin<3, kWaveBlock>((uint64_t)ob + kfirst, kcount, regs);
       rd.template stage_end<3, kWaveBlock>(regs, bit0, smem);
-      __syncthreads();
+      wave_lds_sync();
     }
   }
   const auto vals = rd.staged_at(bit0, smem);
@@ -2221,9 +2234,15 @@ __device__ __forceinline__ void body_select_scatter_wave(const KArgs& a, const N
   uint64_t word = 0;
   if (lane < W && w * 64 < rows) word = BitsReader(nd.sel, a, invert).word(w);
   const T fill = (T)nd.aux;
-  if ((nd.flags & NF_WRITE_NULLS) && lane < W && w * 64 < rows)
-    reinterpret_cast<uint64_t*>(a.out + nd.aux_off)[w] = invert ? ~word & (w * 64 + 64 > rows ? wmask((uint32_t)(rows - w * 64)) : ~0ull) : word;
+  // the copy of the bitmap goes out behind everything the tile loads: a wave's
+  // loads return in order with its stores, so a load issued behind a store
+  // waits for that store to be acknowledged
+  auto write_nulls = [&]() {
+    if ((nd.flags & NF_WRITE_NULLS) && lane < W && w * 64 < rows)
+      reinterpret_cast<uint64_t*>(a.out + nd.aux_off)[w] = invert ? ~word & (w * 64 + 64 > rows ? wmask((uint32_t)(rows - w * 64)) : ~0ull) : word;
+  };
   if (n == 0) {  // nothing selected (or nothing to select from): a fill
+    write_nulls();
     Vec16<ES> x;
 #pragma unroll
     for (uint32_t j = 0; j < V; ++j) x.v[j] = fill;
@@ -2233,6 +2252,7 @@ __device__ __forceinline__ void body_select_scatter_wave(const KArgs& a, const N
   }
   if (nested) {
     with_reader<ES>(nd.c1, a, [&](auto rd) { wave_select_nested<ES>(a, nd, rd, smem, word, base, n, tile_rows, dst, fill); });
+    write_nulls();
     return;
   }
   with_reader<ES>(nd.c1, a, [&](auto rd) {
@@ -2241,9 +2261,10 @@ __device__ __forceinline__ void body_select_scatter_wave(const KArgs& a, const N
     regs.nvec = 0;
     uint32_t bit0 = 0;
     if (staged) bit0 = rd.template stage_begin<3, kWaveBlock>(base, n, regs);
+    write_nulls();  // behind the loads of the staged values
     tile_rank_scan32<W>(word, s_bits, s_pref, nullptr);
     const auto vals = rd.template stage_end<3, kWaveBlock>(regs, bit0, smem);
-    __syncthreads();
+    wave_lds_sync();
     const uint32_t last = n - 1;
     if (!staged) {  // a tile denser than the column's average: its values row by row from global memory
 #pragma unroll 1
@@ -2668,9 +2689,6 @@ __device__ __forceinline__ void body_dict_str(const KArgs& a, const NodeDesc& nd
   uint64_t* s_words = reinterpret_cast<uint64_t*>(mine + kDictStrWaveStage);  // words of tile wv (0 .. 31) and of tile wv + 16 (32 .. 63)
   uint32_t* s_pref = reinterpret_cast<uint32_t*>(mine + kDictStrWaveStage + 64 * 8);  // rank of each word's first row; [64], [65]: ranks behind the tiles
   {
-    if (scatter && (nd.flags & NF_WRITE_NULLS) && tl < n_t && my_w * 64 < rows)
-      reinterpret_cast<uint64_t*>(a.out + nd.aux_off)[my_w] =
-          invert ? ~word & (my_w * 64 + 64 > rows ? wmask((uint32_t)(rows - my_w * 64)) : ~0ull) : word;
     const uint32_t pc = (uint32_t)__popcll(word);
     const uint32_t incl = wave_incl_scan(pc);
     const uint32_t low = (uint32_t)__builtin_amdgcn_readlane((int)incl, 31);  // rows selected in the first of the two tiles
@@ -2710,6 +2728,11 @@ __device__ __forceinline__ void body_dict_str(const KArgs& a, const NodeDesc& nd
   };
   Slice x0 = slice_of(0), x1 = slice_of(1);
   u32x4 q0 = issue(x0), q1 = issue(x1);
+  // the copy of the bitmap goes out behind the first loads: a wave's loads return
+  // in order with its stores
+  if (scatter && (nd.flags & NF_WRITE_NULLS) && tl < n_t && my_w * 64 < rows)
+    reinterpret_cast<uint64_t*>(a.out + nd.aux_off)[my_w] =
+        invert ? ~word & (my_w * 64 + 64 > rows ? wmask((uint32_t)(rows - my_w * 64)) : ~0ull) : word;
   for (uint32_t sl = 0; sl < 8; ++sl) {  // wave uniform
     const uint32_t half = sl >> 2, m = sl & 3u, tl = wv + kDictStrWaves * half;
     if (tl >= n_t) break;
@@ -3218,6 +3241,11 @@ NBL_KERNEL_ES(k_frame_unpack, K_FRAME_UNPACK)
 #undef NBL_KERNEL
 template <int ES>
 __global__ __launch_bounds__(kWaveBlock, 8) void k_select_scatter_wave(KArgs a) {
+  // One tile per workgroup, on purpose: a wave's vector loads return in order
+  // with its stores, so a second tile's first loads would queue behind the
+  // first tile's 16 KiB of stores (two or four tiles per workgroup, consecutive
+  // or a grid apart: 363 -> 396-412 us on the 5,000-column stripe), while a new
+  // workgroup starts with an empty queue.
   __shared__ __align__(16) uint8_t smem[kWaveSmemBytes];
   const uint32_t node = sload32(&a.tiles[blockIdx.x].node);
   const uint32_t tile = sload32(&a.tiles[blockIdx.x].tile) & kTileMask;
