@@ -81,6 +81,41 @@ def test_nullable_count_mismatch(gpu):
         _decode_expect_device_data([enc], "selected-row count")
 
 
+def test_nullable_count_mismatch_over_the_lds_dictionary_kernels(gpu):
+    """The same mismatch where the values child is a Dictionary gathered inside the rank scatter by the kernels that
+    keep the alphabet in LDS (8-byte numbers; strings in compact form): ranks past the index column are clamped."""
+    from nimble_amd import workloads as WL
+
+    rng = np.random.default_rng(3)
+    rows = 150_000
+    mask = rng.random(rows) < 0.5
+    nulls = E.encode(E.Trivial(), mask, W.BOOL)
+    strings = E.StringColumn.from_list(WL.random_alphabet(rng, 4000).to_list()[:3000])
+    numbers = (rng.permutation(1 << 20)[:3000].astype(np.int64) << 20)
+    for delta in (-700, +700):
+        nn = int(mask.sum()) + delta
+        idx = rng.integers(0, 3000, nn)
+        idx[:3000] = np.arange(3000)  # every entry used: the encoder keeps the alphabet whole
+        encs = []
+        for dt, alpha, spec in ((W.STRING, strings, E.Dictionary(alphabet=E.Trivial(lengths=E.FixedBitWidth()), indices=E.FixedBitWidth())),
+                                (W.INT64, numbers, E.Dictionary(alphabet=E.Trivial(), indices=E.FixedBitWidth()))):
+            data = E.encode_dictionary_from_indices(spec, alpha, idx, dt)
+            encs.append(E.prefix(W.NULLABLE, dt, rows) + struct.pack("<I", len(data)) + data + nulls)
+        for options in (dict(lds_dictionary_min_tiles=1), dict(lds_dictionary_min_tiles=1, per_kernel=True), dict(no_lds_dictionary=True)):
+            plan = Plan.from_encodings(encs, **options)
+            names = [l[0] for l in plan.launches()]
+            if options.get("per_kernel"):
+                assert "k_dict_str<8>" in names and "k_dict_lds<8>" in names
+            dec = BatchDecoder(plan)
+            dec.stage()
+            dec.decode()
+            with pytest.raises(capi.NimbleError, match="selected-row count") as ei:
+                dec.status()
+            assert ei.value.status == capi.NBL_ERR_DEVICE_DATA
+            dec.fetch()
+            plan.close()
+
+
 def test_varint_truncated(gpu):
     v = np.random.default_rng(3).integers(0, 1 << 40, 5000).astype(np.uint64)
     enc = E.encode(E.Varint(), v, W.INT64)
