@@ -59,7 +59,10 @@ int main(int argc, char** argv) {
   };
   if (pipeline) {
     try {
-      GpuEncodingFactory factory;
+      DecodingStats stats;
+      Options fopts;
+      fopts.decodingStats = &stats;
+      GpuEncodingFactory factory(fopts);
       struct Stripe {
         std::vector<std::unique_ptr<Encoding>> encs;
         std::vector<std::unique_ptr<char[]>> strings;
@@ -134,6 +137,12 @@ int main(int argc, char** argv) {
       if (drained > kWarm)
         printf("steady state (stripes %d..%d): %.2f ms per stripe, end-to-end %.2f GB/s\n", kWarm, drained - 1,
                ms(t_steady, t1) / (drained - kWarm), (bytes - bytes_at_steady) / 1e6 / ms(t_steady, t1));
+      // what a batch costs the thread that makes it (stage, plan, launch, wait for the status) and the device
+      const double nb = (double)std::max<uint64_t>(1, stats.decodeCPUTimeNanos.count());
+      printf("per batch: host %.2f ms (min %.2f, max %.2f; planning %.2f ms, inflating %.2f ms), device %.3f ms, staged %.1f MB, decoded %.1f MB\n",
+             stats.decodeCPUTimeNanos.sum() / nb / 1e6, stats.decodeCPUTimeNanos.min() / 1e6, stats.decodeCPUTimeNanos.max() / 1e6,
+             stats.planNanos.sum() / nb / 1e6, stats.decompressCPUTimeNanos.sum() / nb / 1e6, stats.deviceNanos.sum() / nb / 1e6,
+             stats.encodedBytes.sum() / nb / 1e6, stats.decodedBytes.sum() / nb / 1e6);
     } catch (const std::exception& e) {
       fprintf(stderr, "error: %s\n", e.what());
       return 1;
