@@ -237,6 +237,20 @@ nbl_status nbl_decode_batch_device(const nbl_plan* plan, const void* d_arena,
  * decodes with the same plan covers the series. */
 nbl_status nbl_decode_status(const nbl_plan* plan, const void* d_work, void* stream);
 
+/*
+ * Copies `bytes` of device memory to pinned host memory by a kernel, asynchronous
+ * on `stream`, for the copy back of a decoded batch into the buffers the
+ * caller's Encoding::materialize (Encoding.h:240-248) is served from.  A
+ * hipMemcpyAsync does the same on a copy engine; which engine a stream gets is
+ * the runtime's choice, and two streams can end up with the copy back of one
+ * and the copy in of the other on the same engine, taking turns.  A kernel
+ * leaves the engines to the copy in, so both directions of the link run at
+ * once whatever else the process has copied.  `host_dst` must be memory the
+ * device can address (hipHostMalloc / hipHostRegister); both pointers 16-byte
+ * aligned.  No allocation, no synchronisation.
+ */
+nbl_status nbl_copy_to_host_async(void* host_dst, const void* dev_src, uint64_t bytes, void* stream);
+
 /* One kernel launch of the plan (for profiling and roofline accounting). */
 typedef struct nbl_launch_info {
   const char* kernel;      /* kernel as a profiler names it, e.g. "k_materialize_fbw<8>",

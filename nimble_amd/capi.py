@@ -26,6 +26,7 @@ EXPORTED_SYMBOLS = (
     "nbl_plan_get_launch", "nbl_last_error", "nbl_build_arch", "nbl_build_source_id",
     "nbl_profile_create", "nbl_profile_free", "nbl_decode_batch_profiled", "nbl_profile_collect",
     "nbl_plan_fingerprint", "nbl_split_stream_ex", "nbl_uncompressed_size", "nbl_uncompress", "nbl_chunk_inflated_size", "nbl_chunk_inflate",
+    "nbl_copy_to_host_async",
 )
 
 
@@ -129,6 +130,8 @@ def lib():
         L.nbl_decode_batch_device.argtypes = [vp, vp, vp, vp, vp]
         L.nbl_decode_status.restype = C.c_int
         L.nbl_decode_status.argtypes = [vp, vp, vp]
+        L.nbl_copy_to_host_async.restype = C.c_int
+        L.nbl_copy_to_host_async.argtypes = [vp, vp, u64, vp]
         L.nbl_plan_get_launch.restype = C.c_int
         L.nbl_plan_get_launch.argtypes = [vp, u32, C.POINTER(NblLaunchInfo)]
         L.nbl_plan_fingerprint.restype = C.c_int

@@ -3334,6 +3334,20 @@ __global__ __launch_bounds__(256, 8) void k_level(KArgs) {
 #undef NBL_OP
 }
 
+// ------------------------------------------------------------------ copy back by kernel
+// Decoded bytes -> pinned host memory, written by the CUs over the host link
+// instead of by a copy engine.  A few resident workgroups are plenty: the link
+// (about 55 GB/s), not the chip, sets the pace, and every wave writes whole
+// 1 KiB runs.  The bytes behind the last 16-byte vector go one by one.
+constexpr uint32_t kCopyOutBlocks = 256;
+__global__ __launch_bounds__(kBlock) void k_copy_to_host(const u32x4* __restrict__ src, u32x4* __restrict__ dst, uint64_t bytes) {
+  const uint64_t n = bytes >> 4;
+  for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
+    dst[i] = __builtin_nontemporal_load(src + i);
+  if (blockIdx.x == 0 && threadIdx.x < (bytes & 15))
+    reinterpret_cast<uint8_t*>(dst)[(n << 4) + threadIdx.x] = reinterpret_cast<const uint8_t*>(src)[(n << 4) + threadIdx.x];
+}
+
 }  // namespace nbl
 
 // ------------------------------------------------------------------ launcher
@@ -3346,6 +3360,16 @@ extern "C" int nbl_phase_read(uint32_t* out, uint32_t n_tiles) {
   return hipMemcpyFromSymbol(out, HIP_SYMBOL(nbl::g_phase), sizeof(uint32_t) * 8 * n_tiles) == hipSuccess ? 0 : -1;
 }
 #endif
+
+extern "C" int nbl_launch_copy_to_host(void* host_dst, const void* dev_src, uint64_t bytes, void* stream) {
+  using namespace nbl;
+  if (bytes == 0) return 0;
+  const uint64_t vectors = bytes >> 4;
+  const uint32_t blocks = (uint32_t)std::min<uint64_t>(kCopyOutBlocks, std::max<uint64_t>(1, (vectors + kBlock - 1) / kBlock));
+  hipLaunchKernelGGL(k_copy_to_host, dim3(blocks), dim3(kBlock), 0, static_cast<hipStream_t>(stream), static_cast<const u32x4*>(dev_src),
+                     static_cast<u32x4*>(host_dst), bytes);
+  return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 
 extern "C" int nbl_launch_kernel(uint32_t kernel, uint32_t es, const nbl::KArgs* args, void* stream) {
   using namespace nbl;

@@ -29,6 +29,7 @@
 #include "nbl_desc.h"
 
 extern "C" int nbl_launch_kernel(uint32_t kernel, uint32_t es, const nbl::KArgs* args, void* stream);
+extern "C" int nbl_launch_copy_to_host(void* host_dst, const void* dev_src, uint64_t bytes, void* stream);
 
 namespace {
 
@@ -1856,6 +1857,17 @@ static nbl_status decode_impl(const nbl_plan* p, nbl_profile* prof, uint32_t ste
 }
 
 extern "C" {
+
+nbl_status nbl_copy_to_host_async(void* host_dst, const void* dev_src, uint64_t bytes, void* stream) {
+  if (bytes == 0) return NBL_OK;
+  if (!host_dst || !dev_src) { g_last_error = "null argument"; return NBL_ERR_ARGUMENT; }
+  if ((reinterpret_cast<uintptr_t>(host_dst) | reinterpret_cast<uintptr_t>(dev_src)) & 15) {
+    g_last_error = "nbl_copy_to_host_async: pointers must be 16-byte aligned";
+    return NBL_ERR_ARGUMENT;
+  }
+  if (nbl_launch_copy_to_host(host_dst, dev_src, bytes, stream) != 0) return hip_fail("copy to host", hipGetLastError());
+  return NBL_OK;
+}
 
 nbl_status nbl_decode_status(const nbl_plan* p, const void* d_work, void* stream) {
   if (!p || !d_work) { g_last_error = "null argument"; return NBL_ERR_ARGUMENT; }

@@ -112,11 +112,12 @@ struct DeviceBuffer {
   void* ptr = nullptr;
   size_t cap = 0;
   // Grows with a quarter of headroom, so a loop over stripes of one shape never
-  // reallocates.  `stream` = the stream whose queued work may still use the old
+  // reallocates.  `streams` = the streams whose queued work may still use the old
   // block (a copy-back of the batch before last): waited for before it is freed.
-  void reserve(size_t n, hipStream_t stream = nullptr) {
+  void reserve(size_t n, std::initializer_list<hipStream_t> streams = {}) {
     if (n <= cap) return;
-    if (ptr && stream) hipCheck(hipStreamSynchronize(stream), "hipStreamSynchronize");
+    if (ptr)
+      for (hipStream_t stream : streams) hipCheck(hipStreamSynchronize(stream), "hipStreamSynchronize");
     if (ptr) hipCheck(hipFree(ptr), "hipFree");
     ptr = nullptr;
     cap = 0;
@@ -175,14 +176,21 @@ class PinnedPool : public std::enable_shared_from_this<PinnedPool> {
 
 }  // namespace
 
-// A context owns two slots, each a stream with device buffers of its own.
-// Consecutive batches alternate slots, so the host-to-device copy and the
-// decode of one stripe run while the decoded output of the stripe before is
-// still on its way back on the other stream (the link is full duplex): the
-// stripe loop of a reader (VeloxReader::loadNextStripe, velox/VeloxReader.cpp:330-351)
+// A context owns two slots, each a stream with device buffers of its own, and
+// one more stream for the copies back.  Consecutive batches alternate slots, so
+// the copy in and the decode of one stripe run while the decoded output of the
+// stripe before is still on its way back (the link is full duplex): the stripe
+// loop of a reader (VeloxReader::loadNextStripe, velox/VeloxReader.cpp:330-351)
 // then pays the longer of the two transfers per stripe instead of their sum.
-// A slot is reused by the batch after next, which queues on the slot's stream
-// behind the copy-back that still reads its output buffer.
+// That holds because the copy back is a kernel (nbl_copy_to_host_async) and
+// not a copy engine's: the runtime gives a stream a copy engine per direction
+// the first time the stream copies that way, and two streams that each copy
+// both ways end up with the copy in of one on the engine of the other's copy
+// back -- the transfers then take turns (tools/link_probe.hip shows both
+// cases).  Here the engines only ever copy in.  Three streams also stay within
+// the four hardware queues a process has, so none waits behind another's
+// kernel.  A slot is reused by the batch after next, whose decode waits for
+// the copy back that still reads the slot's output.
 class GpuContext {
  public:
   struct Slot {
@@ -190,18 +198,23 @@ class GpuContext {
     hipStream_t stream = nullptr;
     DeviceBuffer arena, out, work;
     hipEvent_t decodeBegin = nullptr, decodeEnd = nullptr;  // created on the first batch that asks for statistics
+    hipEvent_t outFree = nullptr;  // on copyOut: the last copy back out of the slot's output has landed
+    bool outBusy = false;          // outFree has been recorded
   };
   explicit GpuContext(int device) : device_(device) {}
   ~GpuContext() {
+    if (copyOut) (void)hipStreamSynchronize(copyOut);
     for (Slot& s : slots_)
       if (s.stream) {
         (void)hipStreamSynchronize(s.stream);
-        if (s.decodeBegin) (void)hipEventDestroy(s.decodeBegin);
-        if (s.decodeEnd) (void)hipEventDestroy(s.decodeEnd);
+        for (hipEvent_t e : {s.decodeBegin, s.decodeEnd, s.outFree})
+          if (e) (void)hipEventDestroy(e);
         (void)hipStreamDestroy(s.stream);
       }
+    if (copyOut) (void)hipStreamDestroy(copyOut);
   }
   int device_;
+  hipStream_t copyOut = nullptr;  // created with the first slot
   std::shared_ptr<PinnedPool> pinned = std::make_shared<PinnedPool>();
   // The slot of the next batch, locked: the one whose turn it is, the other one
   // when that is busy (two callers never queue on one slot while the other idles),
@@ -219,7 +232,12 @@ class GpuContext {
       lock = std::unique_lock<std::mutex>(slot->mu);
     }
     hipCheck(hipSetDevice(device_), "hipSetDevice");
-    if (!slot->stream) hipCheck(hipStreamCreateWithFlags(&slot->stream, hipStreamNonBlocking), "hipStreamCreate");
+    if (!slot->stream) {
+      hipCheck(hipStreamCreateWithFlags(&slot->stream, hipStreamNonBlocking), "hipStreamCreate");
+      hipCheck(hipEventCreateWithFlags(&slot->outFree, hipEventDisableTiming), "hipEventCreate");
+      std::lock_guard<std::mutex> once(copyMu_);
+      if (!copyOut) hipCheck(hipStreamCreateWithFlags(&copyOut, hipStreamNonBlocking), "hipStreamCreate");
+    }
     return lock;
   }
 
@@ -227,6 +245,7 @@ class GpuContext {
   static constexpr unsigned kSlots = 2;
   Slot slots_[kSlots];
   std::atomic<unsigned> next_{0};
+  std::mutex copyMu_;
 };
 
 namespace {
@@ -251,7 +270,8 @@ class OutputCopy {
     constexpr uint64_t kSlice = 32ull << 20;
     for (uint64_t off = 0; off < bytes; off += kSlice) {
       const uint64_t len = std::min(kSlice, bytes - off);
-      hipCheck(hipMemcpyAsync(host_.get() + off, static_cast<const uint8_t*>(dev) + off, len, hipMemcpyDeviceToHost, stream), "D2H");
+      // by kernel: the copy engines stay with the copies in, whatever engine the runtime gave this stream
+      check(nbl_copy_to_host_async(host_.get() + off, static_cast<const uint8_t*>(dev) + off, len, stream));
       hipEvent_t ev = nullptr;
       hipCheck(hipEventCreateWithFlags(&ev, hipEventDisableTiming), "hipEventCreate");
       events_.push_back(ev);
@@ -602,7 +622,7 @@ StagedBatch stageBatch(GpuContext& ctx, GpuContext::Slot& slot, const std::vecto
     total += (sizes[i] + 15) & ~uint64_t(15);
   }
   b.staging = ctx.pinned->acquire(total);
-  slot.arena.reserve(total + 64, slot.stream);  // + the slop nbl_plan_info::arena_bytes asks for behind the last chunk
+  slot.arena.reserve(total + 64, {slot.stream});  // + the slop nbl_plan_info::arena_bytes asks for behind the last chunk
   constexpr uint64_t kSlice = 32ull << 20;
   for (size_t first = 0; first < chunks.size();) {
     size_t last = first;
@@ -639,6 +659,16 @@ StagedBatch stageBatch(GpuContext& ctx, GpuContext::Slot& slot, const std::vecto
   return b;
 }
 
+// A batch that fails half way leaves copies and kernels queued that still use its pinned staging block and the
+// slot's buffers: they are waited for before the error leaves the call (and the block goes back to the pool).
+struct DrainOnError {
+  GpuContext::Slot& slot;
+  bool armed = true;
+  ~DrainOnError() {
+    if (armed) (void)hipStreamSynchronize(slot.stream);
+  }
+};
+
 // plan + H2D + decode + D2H for chunks given as (pointer, size) pairs.
 std::vector<std::unique_ptr<Encoding>> decodeChunks(GpuContext& ctx, const std::vector<std::string_view>& chunks,
                                                     const GpuEncodingFactory::StringBufferFactory& sbf, const Options& opts) {
@@ -652,21 +682,27 @@ std::vector<std::unique_ptr<Encoding>> decodeChunks(GpuContext& ctx, const std::
     GpuContext::Slot& slot = *slotp;
     BatchTimer timer(opts.decodingStats);
     uint64_t stagedBytes = 0;
+    DrainOnError drain{slot};
     b = stageBatch(ctx, slot, chunks, opts, timer, stagedBytes);
     hostOut = std::make_shared<OutputCopy>(ctx.pinned->acquire(b.info.out_bytes));
-    slot.out.reserve(b.info.out_bytes, slot.stream);
-    slot.work.reserve(b.info.work_bytes, slot.stream);
+    slot.out.reserve(b.info.out_bytes, {ctx.copyOut, slot.stream});
+    slot.work.reserve(b.info.work_bytes, {slot.stream});
     check(nbl_plan_upload(b.plan.p, slot.work.ptr, slot.stream));
+    if (slot.outBusy) hipCheck(hipStreamWaitEvent(slot.stream, slot.outFree, 0), "hipStreamWaitEvent");
     timer.deviceBegin(slot);
     check(nbl_decode_batch_device(b.plan.p, slot.arena.ptr, slot.out.ptr, slot.work.ptr, slot.stream));
     timer.deviceEnd(slot);
     // synchronises the slot's stream: inconsistent payloads are reported before anything is handed out
     check(nbl_decode_status(b.plan.p, slot.work.ptr, slot.stream));
+    drain.armed = false;
     timer.finish(slot, b.info, stagedBytes);
     // the copy back runs on while the caller already reads the first chunks and
-    // while the next batch is copied in and decoded on the other slot; the batch
-    // after that queues behind this copy on this slot's stream
-    hostOut->enqueue(slot.out.ptr, b.info.out_bytes, slot.stream);
+    // while the next batch is copied in and decoded on the other slot; the decode
+    // of the batch after that, on this slot again, waits for outFree (the slot's
+    // stream is idle here: the status call has synchronised it)
+    hostOut->enqueue(slot.out.ptr, b.info.out_bytes, ctx.copyOut);
+    hipCheck(hipEventRecord(slot.outFree, ctx.copyOut), "hipEventRecord");
+    slot.outBusy = true;
   }
   result.reserve(chunks.size());
   for (uint32_t c = 0; c < chunks.size(); ++c) {
@@ -705,8 +741,9 @@ std::unique_ptr<DeviceBatch> decodeChunksToDevice(const std::shared_ptr<GpuConte
     GpuContext::Slot& slot = *slotp;
     BatchTimer timer(opts.decodingStats);
     uint64_t stagedBytes = 0;
+    DrainOnError drain{slot};
     b = stageBatch(ctx, slot, chunks, opts, timer, stagedBytes);
-    slot.work.reserve(b.info.work_bytes, slot.stream);
+    slot.work.reserve(b.info.work_bytes, {slot.stream});
     batch->out.reserve(b.info.out_bytes);   // owned by the batch: it outlives this call
     batch->outBytes = b.info.out_bytes;
     batch->stream_ = slot.stream;
@@ -715,6 +752,7 @@ std::unique_ptr<DeviceBatch> decodeChunksToDevice(const std::shared_ptr<GpuConte
     check(nbl_decode_batch_device(b.plan.p, slot.arena.ptr, batch->out.ptr, slot.work.ptr, slot.stream));
     timer.deviceEnd(slot);
     check(nbl_decode_status(b.plan.p, slot.work.ptr, slot.stream));  // synchronises the slot's stream
+    drain.armed = false;
     timer.finish(slot, b.info, stagedBytes);
   }
   batch->layouts.resize(chunks.size());

@@ -386,3 +386,31 @@ def test_output_copy_in_slices(factory):
         d.skip(rows - 1000)
         d.next(1000, out2)
         assert np.array_equal(out2, cols_b[0][-1000:])
+
+
+def test_copy_to_host_by_kernel(gpu):
+    """nbl_copy_to_host_async -- the copy back of a decoded batch without a copy
+    engine -- moves every byte, the ragged tail behind the last 16-byte vector
+    included, touches nothing behind it, and refuses pointers it cannot vector."""
+    import ctypes as C
+
+    import torch
+
+    from nimble_amd import capi
+
+    lib = capi.lib()
+    rng = np.random.default_rng(5)
+    cap = (64 << 20) + 64
+    host = torch.empty(cap, dtype=torch.uint8).pin_memory()
+    src = torch.from_numpy(rng.integers(0, 256, cap, dtype=np.uint8)).to("cuda:0")
+    stream = torch.cuda.Stream()
+    for n in (0, 1, 15, 16, 17, 4096 + 5, (1 << 20) + 3, 64 << 20):
+        host.fill_(0xA5)
+        torch.cuda.synchronize()
+        capi.check(lib.nbl_copy_to_host_async(C.c_void_p(host.data_ptr()), C.c_void_p(src.data_ptr()), n, C.c_void_p(stream.cuda_stream)))
+        stream.synchronize()
+        got = host.numpy()
+        assert np.array_equal(got[:n], src[:n].cpu().numpy()), n
+        assert (got[n:n + 64] == 0xA5).all(), n
+    assert lib.nbl_copy_to_host_async(C.c_void_p(host.data_ptr() + 4), C.c_void_p(src.data_ptr()), 64, None) == capi.NBL_ERR_ARGUMENT
+    assert b"16-byte" in lib.nbl_last_error()

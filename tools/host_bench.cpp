@@ -15,6 +15,7 @@
 #include <chrono>
 #include <cstdio>
 #include <algorithm>
+#include <array>
 #include <cstdlib>
 #include <memory>
 #include <thread>
@@ -74,12 +75,16 @@ int main(int argc, char** argv) {
       std::string error;
       { auto warm = factory.createBatch(chunks, [](uint32_t n) -> void* { static std::vector<std::unique_ptr<char[]>> keep; keep.push_back(std::make_unique<char[]>(n ? n : 1)); return keep.back().get(); }, factory.options()); }
       const auto t0 = Clock::now();
+      // when each stripe's createBatch began and ended and when its drain began and ended, ms after t0
+      std::vector<std::array<double, 4>> when((size_t)iters);
       std::thread loader([&] {
         try {
           for (int it = 0; it < iters; ++it) {
             auto st = std::make_unique<Stripe>();
             auto* strings = &st->strings;
+            when[(size_t)it][0] = ms(t0, Clock::now());
             st->encs = factory.createBatch(chunks, [strings](uint32_t n) -> void* { strings->push_back(std::make_unique<char[]>(n ? n : 1)); return strings->back().get(); }, factory.options());
+            when[(size_t)it][1] = ms(t0, Clock::now());
             std::unique_lock<std::mutex> lock(mu);
             cv.wait(lock, [&] { return ready.size() < 1; });
             ready.push_back(std::move(st));
@@ -94,7 +99,7 @@ int main(int argc, char** argv) {
       std::vector<std::vector<uint8_t>> sinks((size_t)readers);
       // the first stripes also pay for the pinned blocks of every stripe in flight (hipHostMalloc of a few GB):
       // the steady-state rate is taken over the stripes after them
-      constexpr int kWarm = 3;
+      constexpr int kWarm = 6;
       int drained = 0;
       Clock::time_point t_steady = t0;
       uint64_t bytes_at_steady = 0;
@@ -108,6 +113,7 @@ int main(int argc, char** argv) {
           ready.pop_front();
           cv.notify_all();
         }
+        when[(size_t)drained][2] = ms(t0, Clock::now());
         std::atomic<size_t> next{0};
         std::atomic<uint64_t> r{0}, b{0};
         auto drain = [&](std::vector<uint8_t>& sink) {
@@ -127,6 +133,7 @@ int main(int argc, char** argv) {
         for (auto& t : pool) t.join();
         rows += r.load();
         bytes += b.load();
+        when[(size_t)drained][3] = ms(t0, Clock::now());
         if (++drained == kWarm) { t_steady = Clock::now(); bytes_at_steady = bytes; }
       }
       loader.join();
@@ -137,6 +144,10 @@ int main(int argc, char** argv) {
       if (drained > kWarm)
         printf("steady state (stripes %d..%d): %.2f ms per stripe, end-to-end %.2f GB/s\n", kWarm, drained - 1,
                ms(t_steady, t1) / (drained - kWarm), (bytes - bytes_at_steady) / 1e6 / ms(t_steady, t1));
+      if (getenv("HOST_BENCH_TIMELINE"))
+        for (int it = 0; it < drained; ++it)
+          printf("stripe %2d: createBatch %8.2f .. %8.2f (%6.2f ms)   drained %8.2f .. %8.2f (%6.2f ms)\n", it, when[(size_t)it][0], when[(size_t)it][1],
+                 when[(size_t)it][1] - when[(size_t)it][0], when[(size_t)it][2], when[(size_t)it][3], when[(size_t)it][3] - when[(size_t)it][2]);
       // what a batch costs the thread that makes it (stage, plan, launch, wait for the status) and the device
       const double nb = (double)std::max<uint64_t>(1, stats.decodeCPUTimeNanos.count());
       printf("per batch: host %.2f ms (min %.2f, max %.2f; planning %.2f ms, inflating %.2f ms), device %.3f ms, staged %.1f MB, decoded %.1f MB\n",

@@ -27,6 +27,7 @@
 // the planner object references the launcher; planning never calls it
 namespace nbl { struct KArgs; }
 extern "C" int nbl_launch_kernel(uint32_t, uint32_t, const nbl::KArgs*, void*) { std::abort(); }
+extern "C" int nbl_launch_copy_to_host(void*, const void*, uint64_t, void*) { std::abort(); }
 
 namespace {
 struct Entry {
