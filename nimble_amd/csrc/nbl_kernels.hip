@@ -3338,8 +3338,12 @@ __global__ __launch_bounds__(256, 8) void k_level(KArgs) {
 // Decoded bytes -> pinned host memory, written by the CUs over the host link
 // instead of by a copy engine.  A few resident workgroups are plenty: the link
 // (about 55 GB/s), not the chip, sets the pace, and every wave writes whole
-// 1 KiB runs.  The bytes behind the last 16-byte vector go one by one.
-constexpr uint32_t kCopyOutBlocks = 256;
+// 1 KiB runs.  64 workgroups keep the link as busy as 256 do (32 no longer),
+// and a decode that runs beside the copy is held up less the fewer writes to
+// the host are pending (2-4 ms beside 256 workgroups, 1-1.5 beside 64, 0.65
+// alone, for the 2.6 GB headline stripe).  The bytes behind the last 16-byte
+// vector go one by one.
+constexpr uint32_t kCopyOutBlocks = 64;
 __global__ __launch_bounds__(kBlock) void k_copy_to_host(const u32x4* __restrict__ src, u32x4* __restrict__ dst, uint64_t bytes) {
   const uint64_t n = bytes >> 4;
   for (uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (uint64_t)gridDim.x * kBlock)
