@@ -435,13 +435,18 @@ def roofline_of(by, workload, rows, launches_per_step_of=1):
 
 def cold_steps(job, torch, device, steps=5, flush_bytes=1 << 30, per_kernel_out=None):
     """Mean device time of a decode whose inputs are not in any cache: between
-    steps 1 GiB is written (four times the 256 MB memory-side cache), outside the
-    events that bracket each decode.  A reader decodes every stripe once, so this
-    is its case; the steady-state loop re-decodes one resident stripe."""
+    steps 1 GiB is written (four times the 256 MB memory-side cache) and then
+    1 GiB of other memory is read, outside the events that bracket each decode.
+    The read pass leaves the caches full of clean foreign lines: without it the
+    decode also pays for writing the flush's dirty lines back (10-40 us on these
+    tables).  A reader decodes every stripe once, so this is its case; the
+    steady-state loop re-decodes one resident stripe."""
     flush = torch.empty(flush_bytes, dtype=torch.uint8, device=device)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     flush.fill_(1)
+    other = torch.zeros(flush_bytes // 8, dtype=torch.int64, device=device)
     for a, b in evs:
+        other.sum()
         a.record()
         job.decode()
         b.record()
@@ -452,9 +457,10 @@ def cold_steps(job, torch, device, steps=5, flush_bytes=1 << 30, per_kernel_out=
         job.profile_begin(steps)
         for s in range(steps):
             flush.fill_(3)
+            other.sum()
             job.decode_profiled(s)
         per_kernel_out.extend(kernel_table(by_kernel(job.launch_list, job.profile_end())))
-    del flush
+    del flush, other
     return ms
 
 
