@@ -240,7 +240,7 @@ nbl_status nbl_decode_status(const nbl_plan* plan, const void* d_work, void* str
 /*
  * Copies `bytes` of device memory to pinned host memory by a kernel, asynchronous
  * on `stream`, for the copy back of a decoded batch into the buffers the
- * caller's Encoding::materialize (Encoding.h:240-248) is served from.  A
+ * caller's Encoding::materialize (Encoding.h:231) is served from.  A
  * hipMemcpyAsync does the same on a copy engine; which engine a stream gets is
  * the runtime's choice, and two streams can end up with the copy back of one
  * and the copy in of the other on the same engine, taking turns.  A kernel
