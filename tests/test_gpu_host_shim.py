@@ -388,6 +388,36 @@ def test_output_copy_in_slices(factory):
         assert np.array_equal(out2, cols_b[0][-1000:])
 
 
+def test_stripes_in_flight_do_not_overwrite_each_other(factory):
+    """Five stripes made back to back, read only afterwards.  Their encodings
+    are tiny (long runs) and their outputs large (256 MB each), so a stripe is
+    made in a fraction of the time its copy back takes: the third stripe gets
+    the device buffers of the first while that one's output is still on its way
+    to the host, and its decode has to wait for that copy."""
+    import host_shim
+
+    rows, n_streams = 4_000_000, 8
+    run = 50_000
+
+    def make(k):
+        cols, streams = [], []
+        for i in range(n_streams):
+            values = (np.arange(rows // run, dtype=np.int64) * 7919 + 1000003 * k + 17 * i) & ((1 << 47) - 1)
+            col = np.repeat(values, run)
+            cols.append(col)
+            streams.append(E.stream([E.encode(E.RLE(), col, W.INT64)]))
+        return cols, streams
+
+    made = [make(k) for k in range(5)]
+    assert sum(len(s) for s in made[0][1]) < 1 << 20  # the encodings really are small
+    stripes = [host_shim.StripeDecoder(factory, streams) for _, streams in made]
+    out = np.zeros(rows, dtype=np.int64)
+    for k, (cols, _) in enumerate(made):
+        for i in range(n_streams):
+            nn, _ = stripes[k].stream(i).next(rows, out)
+            assert nn == rows and np.array_equal(out, cols[i]), (k, i)
+
+
 def test_copy_to_host_by_kernel(gpu):
     """nbl_copy_to_host_async -- the copy back of a decoded batch without a copy
     engine -- moves every byte, the ragged tail behind the last 16-byte vector
