@@ -7,9 +7,12 @@
 #include <cstring>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <exception>
+#include <functional>
 #include <mutex>
 #include <thread>
+#include <memory>
 #include <utility>
 #include <vector>
 
@@ -502,31 +505,82 @@ class GpuEncodingView final : public EncodingView {
   std::shared_ptr<std::vector<std::unique_ptr<char[]>>> strings_;
 };
 
-// fn(i) for i in [0, n) on a few threads when there is enough to move; an
-// exception of any worker is rethrown on the caller
-template <typename F>
-void parallelFor(size_t n, uint64_t bytes, F&& fn) {
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  const size_t workers = std::min<size_t>({n, (size_t)std::min(hw, 16u), (size_t)(bytes >> 22) + 1});  // >= 4 MiB per worker
+// A few threads that stay around between batches: a stripe is staged in slices
+// of 32 MiB, each a parallel copy of well under a millisecond, and starting
+// sixteen threads takes a good part of that.  One job at a time; a caller that
+// finds the pool busy (two batches staged at once) starts threads of its own.
+class WorkerPool {
+ public:
+  static WorkerPool& instance() {
+    static WorkerPool pool;
+    return pool;
+  }
+  // job() on `workers` threads, the caller being one of them; false (nothing run) when the pool is taken
+  bool run(size_t workers, const std::function<void()>& job) {
+    std::unique_lock<std::mutex> turn(jobMu_, std::try_to_lock);
+    if (!turn.owns_lock()) return false;
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      while (threads_.size() + 1 < workers) threads_.emplace_back([this] { work(); });
+      job_ = &job;
+      wanted_ = workers - 1;
+      taken_ = finished_ = 0;
+      ++generation_;
+    }
+    wake_.notify_all();
+    job();
+    std::unique_lock<std::mutex> lock(mu_);
+    done_.wait(lock, [&] { return finished_ == wanted_; });
+    job_ = nullptr;
+    return true;
+  }
+
+ private:
+  WorkerPool() = default;
+  ~WorkerPool() {
+    {
+      std::lock_guard<std::mutex> lock(mu_);
+      stop_ = true;
+    }
+    wake_.notify_all();
+    for (auto& t : threads_) t.join();
+  }
+  void work() {
+    uint64_t seen = 0;
+    std::unique_lock<std::mutex> lock(mu_);
+    for (;;) {
+      wake_.wait(lock, [&] { return stop_ || generation_ != seen; });
+      if (stop_) return;
+      seen = generation_;
+      if (taken_ >= wanted_) continue;  // the job has the threads it asked for
+      ++taken_;
+      const std::function<void()>* job = job_;
+      lock.unlock();
+      (*job)();
+      lock.lock();
+      if (++finished_ == wanted_) done_.notify_all();
+    }
+  }
+  std::mutex jobMu_, mu_;
+  std::condition_variable wake_, done_;
+  std::vector<std::thread> threads_;
+  const std::function<void()>* job_ = nullptr;
+  size_t wanted_ = 0, taken_ = 0, finished_ = 0;
+  uint64_t generation_ = 0;
+  bool stop_ = false;
+};
+
+// job() on `workers` threads, the caller being one of them: the pool's when it is free, else threads of its own
+void parallelRun(size_t workers, const std::function<void()>& job) {
   if (workers <= 1) {
-    for (size_t i = 0; i < n; ++i) fn(i);
+    job();
     return;
   }
-  std::atomic<size_t> next{0};
-  std::exception_ptr error;
-  std::mutex errorMu;
-  std::vector<std::thread> pool;
-  for (size_t w = 0; w < workers; ++w)
-    pool.emplace_back([&] {
-      try {
-        for (size_t i = next++; i < n; i = next++) fn(i);
-      } catch (...) {
-        std::lock_guard<std::mutex> lock(errorMu);
-        if (!error) error = std::current_exception();
-      }
-    });
-  for (auto& t : pool) t.join();
-  if (error) std::rethrow_exception(error);
+  if (WorkerPool::instance().run(workers, job)) return;
+  std::vector<std::thread> own;
+  for (size_t w = 1; w < workers; ++w) own.emplace_back(job);
+  job();
+  for (auto& t : own) t.join();
 }
 
 struct PlanHolder {
@@ -623,33 +677,94 @@ StagedBatch stageBatch(GpuContext& ctx, GpuContext::Slot& slot, const std::vecto
   }
   b.staging = ctx.pinned->acquire(total);
   slot.arena.reserve(total + 64, {slot.stream});  // + the slop nbl_plan_info::arena_bytes asks for behind the last chunk
-  constexpr uint64_t kSlice = 32ull << 20;
+  // Slices of whole chunks, about 32 MiB each; a chunk to inflate is one task, a chunk to copy is cut into
+  // pieces, so that a slice of three or four large chunks still keeps every thread busy.  The tasks of all
+  // slices are one list that the worker threads take from in order, and the calling thread sends a slice off as
+  // soon as its last task is done: the copy engine moves slice k while the threads fill the slices behind it,
+  // and a stripe of compressed chunks inflates on all threads instead of on as many as a slice has chunks.
+  constexpr uint64_t kSlice = 32ull << 20, kPiece = 2ull << 20;
+  struct Task { size_t chunk, slice; uint64_t off, len; };
+  struct Slice { size_t first; uint64_t bytes; };
+  std::vector<Task> tasks;
+  std::vector<Slice> slices;
   for (size_t first = 0; first < chunks.size();) {
     size_t last = first;
     uint64_t bytes = 0;
     while (last < chunks.size() && (bytes == 0 || bytes + sizes[last] <= kSlice)) bytes += (sizes[last++] + 15) & ~uint64_t(15);
-    const auto phase = StatClock::now();
-    parallelFor(last - first, bytes, [&](size_t k) {
-      const size_t i = first + k;
-      const auto t = StatClock::now();
-      if (inflate[i]) {
-        uint64_t written = 0;
-        check(nbl_chunk_inflate(reinterpret_cast<const uint8_t*>(chunks[i].data()), chunks[i].size(), &o, b.staging.get() + offs[i],
-                                sizes[i], &written));
-      } else {
-        memcpy(b.staging.get() + offs[i], chunks[i].data(), chunks[i].size());
-      }
-      if (timer.stats) {
-        const uint64_t ns = nanosSince(t);
-        timer.taskNanos.fetch_add(ns, std::memory_order_relaxed);
-        if (inflate[i]) timer.stats->decompressCPUTimeNanos.increment(ns);
-      }
-    });
-    timer.phaseNanos += nanosSince(phase);
-    hipCheck(hipMemcpyAsync(static_cast<uint8_t*>(slot.arena.ptr) + offs[first], b.staging.get() + offs[first], bytes,
-                            hipMemcpyHostToDevice, slot.stream), "H2D");
+    for (size_t i = first; i < last; ++i) {
+      if (inflate[i]) { tasks.push_back(Task{i, slices.size(), 0, 0}); continue; }
+      for (uint64_t at = 0; at < chunks[i].size(); at += kPiece)
+        tasks.push_back(Task{i, slices.size(), at, std::min<uint64_t>(kPiece, chunks[i].size() - at)});
+    }
+    slices.push_back(Slice{first, bytes});
     first = last;
   }
+  std::unique_ptr<std::atomic<uint32_t>[]> left(new std::atomic<uint32_t>[slices.size()]);  // tasks of the slice not yet done
+  for (size_t k = 0; k < slices.size(); ++k) left[k].store(0, std::memory_order_relaxed);
+  for (const Task& t : tasks) left[t.slice].fetch_add(1, std::memory_order_relaxed);
+  auto run_task = [&](const Task& task) {
+    const size_t i = task.chunk;
+    const auto t = StatClock::now();
+    if (inflate[i]) {
+      uint64_t written = 0;
+      check(nbl_chunk_inflate(reinterpret_cast<const uint8_t*>(chunks[i].data()), chunks[i].size(), &o, b.staging.get() + offs[i],
+                              sizes[i], &written));
+    } else {
+      memcpy(b.staging.get() + offs[i] + task.off, chunks[i].data() + task.off, task.len);
+    }
+    if (timer.stats) {
+      const uint64_t ns = nanosSince(t);
+      timer.taskNanos.fetch_add(ns, std::memory_order_relaxed);
+      if (inflate[i]) timer.stats->decompressCPUTimeNanos.increment(ns);
+    }
+  };
+  auto send = [&](const Slice& sl) {
+    hipCheck(hipMemcpyAsync(static_cast<uint8_t*>(slot.arena.ptr) + offs[sl.first], b.staging.get() + offs[sl.first], sl.bytes,
+                            hipMemcpyHostToDevice, slot.stream), "H2D");
+  };
+  const auto phase = StatClock::now();
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  const size_t helpers = std::min<size_t>({tasks.size(), (size_t)std::min(hw, 16u), (size_t)(total >> 21)});  // >= 2 MiB per thread
+  if (helpers <= 1) {
+    size_t k = 0;
+    for (size_t s = 0; s < slices.size(); ++s) {
+      for (; k < tasks.size() && tasks[k].slice == s; ++k) run_task(tasks[k]);
+      send(slices[s]);
+    }
+  } else {
+    std::atomic<size_t> next{0};
+    std::atomic<bool> failed{false};
+    std::exception_ptr error;
+    std::mutex errorMu;
+    const std::thread::id caller = std::this_thread::get_id();
+    auto fail = [&] {
+      std::lock_guard<std::mutex> lock(errorMu);
+      if (!error) error = std::current_exception();
+      failed.store(true, std::memory_order_release);
+    };
+    parallelRun(helpers + 1, [&] {
+      try {
+        if (std::this_thread::get_id() == caller) {  // sends the slices off, in order, as they fill
+          for (size_t s = 0; s < slices.size(); ++s) {
+            while (left[s].load(std::memory_order_acquire) != 0) {
+              if (failed.load(std::memory_order_acquire)) return;
+              std::this_thread::yield();
+            }
+            send(slices[s]);
+          }
+        } else {
+          for (size_t k = next++; k < tasks.size() && !failed.load(std::memory_order_relaxed); k = next++) {
+            run_task(tasks[k]);
+            left[tasks[k].slice].fetch_sub(1, std::memory_order_release);
+          }
+        }
+      } catch (...) {
+        fail();
+      }
+    });
+    if (error) std::rethrow_exception(error);
+  }
+  timer.phaseNanos += nanosSince(phase);
   const auto planBegin = StatClock::now();
   check(nbl_plan_batch(b.staging.get(), offs.data(), sizes.data(), (uint32_t)chunks.size(), &o, &b.plan.p));
   if (timer.stats) timer.stats->planNanos.increment(nanosSince(planBegin));
