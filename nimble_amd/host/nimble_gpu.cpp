@@ -318,32 +318,20 @@ class GpuEncoding final : public Encoding {
       end_ = std::max(end_, lay.dict_alphabet_offset + (uint64_t)lay.dict_size * lay.elem_bytes);
       if (lay.dict_indices_rows) end_ = std::max(end_, lay.dict_indices_offset + lay.dict_indices_rows * 4);
     }
-    // strings and dictionaries are read right here; plain columns wait at their first read
-    if (lay.data_type == (uint8_t)DataType::String || lay.has_dictionary) arrived();
+    // Nothing of the output block is read here: every read path waits for the chunk's part of it first
+    // (arrived()), and the work a string chunk needs once -- its bytes copied into the caller's buffer, every
+    // view checked against it, the dictionary's entries as string_views -- is done behind that wait, by the
+    // thread that reads the chunk first.  The batch is handed out without waiting for the copy back, and the
+    // readers of a stripe share that work instead of the thread that made the batch doing all of it.
     if (lay.data_type == (uint8_t)DataType::String) {
       // string bytes live in memory the caller's factory hands out, as the
-      // reference's string encodings do (TrivialEncoding.cpp:129-135)
-      char* dst = lay.string_bytes ? static_cast<char*>(sbf(static_cast<uint32_t>(lay.string_bytes))) : nullptr;
-      if (lay.string_bytes) memcpy(dst, hostOut + lay.string_offset, lay.string_bytes);
-      strings_ = dst;
-      const uint64_t* views = reinterpret_cast<const uint64_t*>(values_);
-      for (uint32_t i = 0; i < lay.rows; ++i) {
-        const uint64_t off = views[i] & 0xFFFFFFFFull, len = views[i] >> 32;
-        if (off + len > lay.string_bytes) throw NimbleError(NBL_ERR_DEVICE_DATA, "string view outside the string buffer");
-      }
+      // reference's string encodings do (TrivialEncoding.cpp:129-135); the factory is called here, on the
+      // thread that creates the encoding
+      strings_ = lay.string_bytes ? static_cast<char*>(sbf(static_cast<uint32_t>(lay.string_bytes))) : nullptr;
     }
     if (lay.has_dictionary) {
       dictAlphabet_ = hostOut + lay.dict_alphabet_offset;
       dictIndices_ = lay.dict_indices_rows ? reinterpret_cast<const uint32_t*>(hostOut + lay.dict_indices_offset) : nullptr;
-      if (lay.data_type == (uint8_t)DataType::String) {  // dictionaryEntries() hands out std::string_view[]
-        const uint64_t* views = reinterpret_cast<const uint64_t*>(dictAlphabet_);
-        dictStrings_.reserve(lay.dict_size);
-        for (uint32_t i = 0; i < lay.dict_size; ++i) {
-          const uint64_t off = views[i] & 0xFFFFFFFFull, len = views[i] >> 32;
-          if (off + len > lay.string_bytes) throw NimbleError(NBL_ERR_DEVICE_DATA, "string view outside the string buffer");
-          dictStrings_.emplace_back(strings_ + off, static_cast<size_t>(len));
-        }
-      }
     }
   }
   bool dictionaryEnabled() const override { return lay_.has_dictionary != 0; }
@@ -353,10 +341,12 @@ class GpuEncoding final : public Encoding {
   }
   const void* dictionaryEntries() const override {
     if (!lay_.has_dictionary) return Encoding::dictionaryEntries();
+    arrived();
     return lay_.data_type == (uint8_t)DataType::String ? static_cast<const void*>(dictStrings_.data()) : dictAlphabet_;
   }
   const void* dictionaryEntry(uint32_t index) const override {
     if (!lay_.has_dictionary || index >= lay_.dict_size) return Encoding::dictionaryEntry(index);
+    arrived();
     if (lay_.data_type == (uint8_t)DataType::String) return &dictStrings_[index];
     return dictAlphabet_ + (size_t)index * es_;
   }
@@ -471,7 +461,30 @@ class GpuEncoding final : public Encoding {
   }
 
   // blocks until this chunk's part of the output block has arrived in host memory
-  void arrived() const { block_->waitFor(end_); }
+  void arrived() const {
+    block_->waitFor(end_);
+    if (lay_.data_type == (uint8_t)DataType::String) std::call_once(stringsOnce_, [this] { takeStrings(); });
+  }
+  // once per chunk, with the chunk's bytes in host memory
+  void takeStrings() const {
+    const uint8_t* hostOut = block_->host();
+    if (lay_.string_bytes) memcpy(strings_, hostOut + lay_.string_offset, lay_.string_bytes);
+    auto check_views = [&](const uint64_t* views, uint64_t n) {
+      for (uint64_t i = 0; i < n; ++i) {
+        const uint64_t off = views[i] & 0xFFFFFFFFull, len = views[i] >> 32;
+        if (off + len > lay_.string_bytes) throw NimbleError(NBL_ERR_DEVICE_DATA, "string view outside the string buffer");
+      }
+    };
+    check_views(reinterpret_cast<const uint64_t*>(values_), lay_.rows);
+    if (lay_.has_dictionary) {  // dictionaryEntries() hands out std::string_view[]
+      const uint64_t* views = reinterpret_cast<const uint64_t*>(dictAlphabet_);
+      check_views(views, lay_.dict_size);
+      dictStrings_.clear();
+      dictStrings_.reserve(lay_.dict_size);
+      for (uint32_t i = 0; i < lay_.dict_size; ++i)
+        dictStrings_.emplace_back(strings_ + (views[i] & 0xFFFFFFFFull), static_cast<size_t>(views[i] >> 32));
+    }
+  }
 
   nbl_chunk_layout lay_;
   std::shared_ptr<const OutputCopy> block_;
@@ -480,10 +493,11 @@ class GpuEncoding final : public Encoding {
   uint32_t row_ = 0;
   const uint8_t* values_ = nullptr;
   const uint8_t* nulls_ = nullptr;
-  const char* strings_ = nullptr;
+  char* strings_ = nullptr;
   const uint8_t* dictAlphabet_ = nullptr;
   const uint32_t* dictIndices_ = nullptr;
-  std::vector<std::string_view> dictStrings_;
+  mutable std::vector<std::string_view> dictStrings_;
+  mutable std::once_flag stringsOnce_;
 };
 
 // EncodingView over a decoded chunk; owns the memory its string views point into.
