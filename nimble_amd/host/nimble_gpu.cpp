@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <atomic>
 #include <chrono>
@@ -160,6 +161,20 @@ class PinnedPool : public std::enable_shared_from_this<PinnedPool> {
     if (!ptr) {
       cap = want + want / 8;
       hipCheck(hipHostMalloc(&ptr, cap, hipHostMallocDefault), "hipHostMalloc");
+      // A new block's pages become resident when they are first touched.  Left to the device's first copy
+      // into the block that costs 160-200 ms for a 1.8 GB stripe (a tenth of the link's rate); touched here,
+      // by the staging threads, about 100 ms, and it is the thread making the batch that waits, not the
+      // readers of the stripe before.  Blocks are recycled, so a loop of stripes pays this for its first
+      // three stripes only.
+      if (cap >= (8u << 20)) {
+        const size_t pages = (cap + 4095) / 4096;
+        std::atomic<size_t> next{0};
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        detail::parallelRun(std::min(hw, 16u), [&] {
+          for (size_t k = next.fetch_add(256); k < pages; k = next.fetch_add(256))
+            for (size_t q = k; q < std::min(pages, k + 256); ++q) static_cast<volatile uint8_t*>(ptr)[q * 4096] = 0;
+        });
+      }
     }
     auto self = shared_from_this();
     return std::shared_ptr<uint8_t>(static_cast<uint8_t*>(ptr), [self, cap](uint8_t* p) { self->release(p, cap); });
