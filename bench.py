@@ -260,7 +260,7 @@ def pcie_inclusive(dec, plan, torch, device, steps=5):
             "link_gbs": round((enc + int(plan.info.out_bytes)) / dt / 1e9, 2)}
 
 
-def pcie_pipelined(plan, torch, device, n_buffers=2, stripes=8):
+def pcie_pipelined(plan, torch, device, n_buffers=2, stripes=16):
     """Host-to-host rate with `n_buffers` stripes in flight: the H2D of one stripe
     overlaps the D2H of the previous one (PCIe is full duplex), which is how a
     reader would drive the path over many stripes.  Two streams: one carries the
